@@ -1,0 +1,31 @@
+"""imagescry_amd -- the embed-and-search hot path of libertininick/imagescry on AMD MI355X (gfx950).
+
+Public surface (same names as the reference where the reference has them):
+
+* `ImageBatch`, `EmbeddingBatch`                 -- reference src/imagescry/data.py:29-144
+* `resize`, `normalize_per_channel`, `to_4d`     -- reference src/imagescry/image/transforms.py
+* `EmbeddingModule`, `ResNet50Embedder`          -- reference src/imagescry/models/embedding.py:27-183
+* `EmbeddingBank`                                -- cosine top-k search (new; see search.py)
+
+All arithmetic runs in hand-written HIP kernels behind the C ABI of include/imagescry_hip.h;
+PyTorch is used for device memory, streams and `torch.distributed` only.
+"""
+
+from imagescry_amd.data import EmbeddingBatch, ImageBatch
+from imagescry_amd.embedding import EmbeddingModule, ResNet50Embedder, l2_normalize_channels
+from imagescry_amd.search import EmbeddingBank, shard_bounds
+from imagescry_amd.transforms import normalize_per_channel, resize, to_4d
+
+__all__ = [
+    "EmbeddingBank",
+    "EmbeddingBatch",
+    "EmbeddingModule",
+    "ResNet50Embedder",
+    "l2_normalize_channels",
+    "ImageBatch",
+    "normalize_per_channel",
+    "resize",
+    "shard_bounds",
+    "to_4d",
+]
+__version__ = "0.1.0"

@@ -1,0 +1,160 @@
+"""ctypes binding of `libimagescry_hip.so` (the C ABI declared in include/imagescry_hip.h).
+
+There is no CPU fallback: if the shared library has not been built, or no HIP device is
+present when a kernel is requested, the call raises.  `imagescry_amd.build` compiles the
+library in-tree with hipcc for gfx950.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from pathlib import Path
+
+import torch
+
+LIB_NAME = "libimagescry_hip.so"
+LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
+
+ISC_U8, ISC_F16, ISC_F32 = 0, 1, 2
+ISC_ACT_NONE, ISC_ACT_RELU, ISC_ACT_GELU = 0, 1, 2
+ISC_TOPK_MAX_K = 120
+
+ISC_OK = 0
+ISC_ERR_INVALID_ARG = -1
+ISC_ERR_UNSUPPORTED = -2
+ISC_ERR_WORKSPACE = -3
+ISC_ERR_LAUNCH = -4
+ISC_ERR_NO_DEVICE = -5
+ISC_ERR_ALIGNMENT = -6
+
+
+class HipLibraryError(RuntimeError):
+    """The HIP library is missing, failed to load, or a kernel launch failed."""
+
+
+# name -> (restype, argtypes); every symbol include/imagescry_hip.h declares
+SIGNATURES: dict[str, tuple[object, list[object]]] = {
+    "isc_abi_version": (c_int, []),
+    "isc_strerror": (c_char_p, [c_int]),
+    "isc_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "isc_channel_stats_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "isc_channel_stats": (
+        c_int,
+        [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    "isc_normalize_clip": (
+        c_int,
+        [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p,
+         c_void_p],
+    ),
+    "isc_resize_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isc_l2norm_channels": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "isc_bank_from_rows": (
+        c_int,
+        [c_void_p, c_int64, c_int, c_int64, c_int, c_float, c_void_p, c_int, c_int64, c_void_p],
+    ),
+    "isc_nchw_to_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isc_conv2d_nhwc": (
+        c_int,
+        [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+         c_void_p, c_void_p],
+    ),
+    "isc_im2col_nchw": (
+        c_int,
+        [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    ),
+    "isc_maxpool_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isc_global_avgpool_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isc_cosine_topk_workspace_bytes": (c_int, [c_int, c_int64, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "isc_cosine_topk": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    "isc_cosine_topk_exhaustive_workspace_bytes": (c_int, [c_int, c_int64, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "isc_cosine_topk_exhaustive": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p,
+         c_void_p, c_size_t, c_void_p],
+    ),
+    "isc_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib: ctypes.CDLL | None = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the in-tree shared library once and attach the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m imagescry_amd.build` (hipcc, gfx950). "
+            "imagescry_amd has no CPU fallback."
+        )
+    try:
+        lib = ctypes.CDLL(str(LIB_PATH))
+    except OSError as exc:  # pragma: no cover - depends on the host's ROCm install
+        raise HipLibraryError(f"could not load {LIB_PATH}: {exc}") from exc
+    missing = [name for name in SIGNATURES if not hasattr(lib, name)]
+    if missing and os.environ.get("ISC_PARTIAL_LIB") == "1":  # bring-up only: bind what exists
+        missing_now, missing = missing, []
+        for name in missing_now:
+            SIGNATURES.pop(name)
+    if missing:
+        raise HipLibraryError(f"{LIB_PATH} does not export {missing}; rebuild it with `python -m imagescry_amd.build`")
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.isc_abi_version() != 1:
+        raise HipLibraryError(f"ABI version mismatch: library reports {lib.isc_abi_version()}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+def strerror(status: int) -> str:
+    return load().isc_strerror(status).decode()
+
+
+def check(status: int, what: str) -> None:
+    """Map a C status code to the exception the reference's Python surface would raise."""
+    if status == ISC_OK:
+        return
+    msg = f"{what}: {strerror(status)} (status {status})"
+    if status in (ISC_ERR_INVALID_ARG, ISC_ERR_UNSUPPORTED, ISC_ERR_ALIGNMENT):
+        raise ValueError(msg)
+    raise HipLibraryError(msg)
+
+
+def require_device(t: torch.Tensor, name: str) -> None:
+    """Kernels only exist for HIP devices; refuse anything else loudly."""
+    if t.device.type != "cuda":
+        raise HipLibraryError(
+            f"{name} is on {t.device}; imagescry_amd runs on MI355X (HIP) devices only and has no CPU fallback"
+        )
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def stream_handle(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.uint8:
+        return ISC_U8
+    if dtype == torch.float16:
+        return ISC_F16
+    if dtype == torch.float32:
+        return ISC_F32
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+INF = math.inf

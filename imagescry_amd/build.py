@@ -1,0 +1,65 @@
+"""Compile the HIP sources under `imagescry_amd/csrc/` into `imagescry_amd/libimagescry_hip.so` for gfx950.
+
+Run as `python -m imagescry_amd.build`.  hipcc cross-compiles without a GPU.  The library is kept in-tree
+(git-ignored) so that it travels with the working copy.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+OBJ = CSRC / "build"
+LIB = PKG / "libimagescry_hip.so"
+ARCH = "gfx950"
+FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found (expected on PATH or at /opt/rocm/bin/hipcc)")
+    return exe
+
+
+def _stale(target: Path, deps: list[Path]) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    hipcc = _hipcc()
+    OBJ.mkdir(exist_ok=True)
+    sources = sorted(CSRC.glob("*.hip"))
+    headers = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "imagescry_hip.h"]
+
+    def compile_one(src: Path) -> Path:
+        obj = OBJ / (src.stem + ".o")
+        if force or _stale(obj, [src, *headers]):
+            cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, sources))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,345 @@
+// Encoder blocks in float32 (include/imagescry_hip.h: isc_conv2d_nhwc, isc_im2col_nchw, isc_maxpool_nhwc,
+// isc_global_avgpool_nhwc, isc_nchw_to_nhwc).
+//
+// isc_conv2d_nhwc is an implicit GEMM on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact float32 products
+// and a k-ordered fma chain, so results agree with a CPU float32 convolution to rounding):
+//
+//     out[pixel][cout] = act( sum_{r,s,c} x[b][ho*stride + r - pad][wo*stride + s - pad][c] * w[cout][r][s][c]
+//                             + bias[cout] + residual[pixel][cout] )
+//
+// Layout.  Activations are NHWC and weights KRSC, so for both GEMM operands the reduction axis (r, s, c) is the
+// contiguous one; one K step is 32 channels (128 bytes) of one filter tap.  The weight tile is the MFMA "A"
+// operand (rows = output channels) and the pixel tile the "B" operand (columns = output pixels): a lane then owns
+// four CONSECUTIVE output channels of one pixel, i.e. one 16-byte store into the NHWC output, and bias /
+// residual are 16-byte loads.  LDS tiles are [rows][128 B] with the 16-byte chunks XOR-swizzled by (row >> 1) & 7
+// (conflict-free ds_read_b128 fragment reads), double buffered, one barrier per K step, next step prefetched
+// into registers while the current one is on the matrix cores.
+#include "isc_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvParams {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* res;
+    float* out;
+    int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo;
+    int M;          // B * Ho * Wo output pixels
+    int K;          // R * S * Cin
+    int cin_steps;  // Cin / 32
+    int ksteps;     // R * S * cin_steps
+    int act;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ISC_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ISC_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    return v;
+}
+
+// TCO output channels x TPIX pixels per workgroup of 4 waves; every wave owns a 64 x 64 sub-tile.
+template <int TCO, int TPIX>
+__global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
+    constexpr int WCO = TCO / 64;          // waves along the output channels
+    constexpr int NA = TCO * 8 / 256;      // 16-byte staging slots per thread, weight tile
+    constexpr int NB = TPIX * 8 / 256;     // ... pixel tile
+    constexpr int A_BYTES = TCO * 128;
+    constexpr int B_BYTES = TPIX * 128;
+    constexpr int BUF_BYTES = A_BYTES + B_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wco = wave % WCO;
+    const int wpix = wave / WCO;
+    const int co0 = blockIdx.x * TCO;
+    const int pix0 = blockIdx.y * TPIX;
+
+    // ---- staging assignment: slot = tid + 256 * i  ->  row (tid >> 3) + 32 * i, physical chunk tid & 7
+    const int srow = tid >> 3;
+    const int lchunk = (tid & 7) ^ ((srow >> 1) & 7);  // logical chunk held by this slot ((32 i) >> 1 is 0 mod 8)
+
+    int a_off[NA];  // element offset of the weight row (clamped to the last output channel)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_off[i] = min(co0 + srow + 32 * i, p.Cout - 1) * p.K + lchunk * 4;
+
+    int b_base[NB];  // element offset of image b
+    int b_hw0[NB];   // (ho * stride - pad) << 16 | (wo * stride - pad) & 0xffff ; rows past M are pushed out of range
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int m = pix0 + srow + 32 * i;
+        if (m < p.M) {
+            const int b = m / (p.Ho * p.Wo);
+            const int rem = m - b * p.Ho * p.Wo;
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            b_base[i] = b * p.H * p.W * p.Cin + lchunk * 4;
+            b_hw0[i] = ((ho * p.stride - p.pad) << 16) | ((wo * p.stride - p.pad) & 0xffff);
+        } else {
+            b_base[i] = 0;
+            b_hw0[i] = (int)0x80008000;  // hi0 = wi0 = -32768: never inside the image
+        }
+    }
+
+    // ---- fragment read offsets
+    const int frow = lane & 15;
+    const int fg = lane >> 4;
+    const int fsw = (lane >> 1) & 7;
+    int foff[2];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) foff[cc] = frow * 128 + (((cc * 4 + fg) ^ fsw) << 4);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 sa[NA], sb[NB];
+
+    auto load_step = [&](int ks) {
+        const int rs = ks / p.cin_steps;
+        const int c0 = (ks - rs * p.cin_steps) * 32;
+        const int r = rs / p.S;
+        const int s = rs - r * p.S;
+        const int koff = rs * p.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) sa[i] = *reinterpret_cast<const u32x4*>(p.w + (size_t)(a_off[i] + koff));
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int hi = (b_hw0[i] >> 16) + r;
+            const int wi = (int)(short)(b_hw0[i] & 0xffff) + s;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (ok) v = *reinterpret_cast<const u32x4*>(p.x + (size_t)(b_base[i] + (hi * p.W + wi) * p.Cin + c0));
+            sb[i] = v;
+        }
+    };
+    auto store_step = [&](int buf) {
+        unsigned char* a = lds + buf * BUF_BYTES + tid * 16;
+        unsigned char* b = a + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(a + 4096 * i) = sa[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(b + 4096 * i) = sb[i];
+    };
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+
+    for (int ks = 0; ks < p.ksteps; ++ks) {
+        const int buf = ks & 1;
+        const bool more = ks + 1 < p.ksteps;
+        if (more) load_step(ks + 1);
+
+        const unsigned char* a_img = lds + buf * BUF_BYTES + wco * 64 * 128;
+        const unsigned char* b_img = lds + buf * BUF_BYTES + A_BYTES + wpix * 64 * 128;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            u32x4 a[4], b[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const u32x4*>(a_img + mi * 2048 + foff[cc]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const u32x4*>(b_img + ni * 2048 + foff[cc]);
+            // element j of every lane's chunk feeds the j-th MFMA: a K-axis permutation shared by both operands
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[mi][j]),
+                                                                           __uint_as_float(b[ni][j]), acc[mi][ni], 0, 0, 0);
+        }
+        if (more) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  16x16 MFMA result: column (pixel) = lane & 15, rows (channels) = 4 * (lane >> 4) + 0..3
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int m = pix0 + wpix * 64 + ni * 16 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int co = co0 + wco * 64 + mi * 16 + fg * 4;
+            if (co >= p.Cout) continue;  // Cout % 4 == 0, so a lane's four channels are in or out together
+            f32x4 v = acc[mi][ni];
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+            const size_t o = (size_t)m * p.Cout + co;
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+            *reinterpret_cast<f32x4*>(p.out + o) = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ x, int C, int HW, int Cpad, size_t total,
+                                                      float* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % Cpad);
+        const size_t pix = i / Cpad;  // b * HW + hw
+        const size_t b = pix / HW;
+        const size_t hw = pix - b * HW;
+        y[i] = c < C ? x[(b * C + c) * HW + hw] : 0.f;
+    }
+}
+
+// patches[m][k], k = (r * S + s) * C + c, four consecutive k per thread (one 16-byte store)
+__global__ __launch_bounds__(256) void k_im2col_nchw(const float* __restrict__ x, int C, int H, int W, int R, int S,
+                                                     int stride, int pad, int Ho, int Wo, int Kpad, size_t total4,
+                                                     float* __restrict__ y) {
+    const int kvec = Kpad / 4;
+    const int kreal = R * S * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int kv = (int)(i % kvec);
+        const size_t m = i / kvec;
+        const int b = (int)(m / ((size_t)Ho * Wo));
+        const int rem = (int)(m - (size_t)b * Ho * Wo);
+        const int ho = rem / Wo, wo = rem - ho * Wo;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kv * 4 + j;
+            float e = 0.f;
+            if (k < kreal) {
+                const int rs = k / C, c = k - rs * C;
+                const int r = rs / S, s = rs - r * S;
+                const int hi = ho * stride + r - pad, wi = wo * stride + s - pad;
+                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                    e = x[(((size_t)b * C + c) * H + hi) * W + wi];
+            }
+            v[j] = e;
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_maxpool_nhwc(const float* __restrict__ x, int H, int W, int C, int R, int stride,
+                                                      int pad, int Ho, int Wo, size_t total4, float* __restrict__ y) {
+    const int cvec = C / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int cv = (int)(i % cvec);
+        const size_t m = i / cvec;
+        const int b = (int)(m / ((size_t)Ho * Wo));
+        const int rem = (int)(m - (size_t)b * Ho * Wo);
+        const int ho = rem / Wo, wo = rem - ho * Wo;
+        f32x4 best = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int r = 0; r < R; ++r) {
+            const int hi = ho * stride + r - pad;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int s = 0; s < R; ++s) {
+                const int wi = wo * stride + s - pad;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + hi) * W + wi) * C + cv * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) best[j] = fmaxf(best[j], v[j]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = best;
+    }
+}
+
+// grid (ceil(C / 256), B): thread = one channel, loop over the HW positions (coalesced across channels)
+__global__ __launch_bounds__(256) void k_global_avgpool_nhwc(const float* __restrict__ x, int HW, int C,
+                                                             float* __restrict__ y) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float* p = x + (size_t)blockIdx.y * HW * C + c;
+    float acc = 0.f;
+    for (int i = 0; i < HW; ++i) acc += p[(size_t)i * C];
+    y[(size_t)blockIdx.y * C + c] = acc / (float)HW;
+}
+
+int stream_grid(size_t items) {
+    size_t blocks = isc_ceil_div(items, (size_t)256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    return blocks == 0 ? 1 : (int)blocks;
+}
+
+}  // namespace
+
+extern "C" int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S,
+                               int stride, int pad, const float* bias, const float* residual, int act, float* out,
+                               void* stream) {
+    ISC_REQUIRE(x && w && out);
+    ISC_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0);
+    ISC_REQUIRE(act == ISC_ACT_NONE || act == ISC_ACT_RELU || act == ISC_ACT_GELU);
+    if (Cin % 32 != 0 || Cout % 4 != 0) return ISC_ERR_UNSUPPORTED;  // pad channels with zeros
+    if (H > 16384 || W > 16384 || pad > 8192) return ISC_ERR_UNSUPPORTED;
+    const int Ho = (H + 2 * pad - R) / stride + 1;
+    const int Wo = (W + 2 * pad - S) / stride + 1;
+    ISC_REQUIRE(Ho > 0 && Wo > 0);
+    const int64_t M = (int64_t)B * Ho * Wo;
+    const int64_t K = (int64_t)R * S * Cin;
+    if ((int64_t)B * H * W * Cin >= (1ll << 31) || M * Cout >= (1ll << 31) || (int64_t)Cout * K >= (1ll << 31))
+        return ISC_ERR_UNSUPPORTED;  // 32-bit element offsets inside the kernel
+    if (!isc_aligned(x, 16) || !isc_aligned(w, 16) || !isc_aligned(out, 16) || (bias && !isc_aligned(bias, 16)) ||
+        (residual && !isc_aligned(residual, 16)))
+        return ISC_ERR_ALIGNMENT;
+    ConvParams p;
+    p.x = x; p.w = w; p.bias = bias; p.res = residual; p.out = out;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+    p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = Cin / 32; p.ksteps = R * S * (Cin / 32); p.act = act;
+    hipStream_t s = isc_stream(stream);
+    if (Cout <= 64) {
+        const dim3 grid(isc_ceil_div(Cout, 64), (unsigned)isc_ceil_div<int64_t>(M, 256));
+        if (grid.y > 65535u * 16u) return ISC_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((k_conv_f32<64, 256>), grid, dim3(256), 0, s, p);
+    } else {
+        const dim3 grid(isc_ceil_div(Cout, 128), (unsigned)isc_ceil_div<int64_t>(M, 128));
+        hipLaunchKernelGGL((k_conv_f32<128, 128>), grid, dim3(256), 0, s, p);
+    }
+    return isc_launch_status();
+}
+
+extern "C" int isc_nchw_to_nhwc(const float* x, int B, int C, int H, int W, int Cpad, float* y, void* stream) {
+    ISC_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C);
+    const size_t total = (size_t)B * H * W * Cpad;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(stream_grid(total)), dim3(256), 0, isc_stream(stream), x, C, H * W, Cpad,
+                       total, y);
+    return isc_launch_status();
+}
+
+extern "C" int isc_im2col_nchw(const float* x, int B, int C, int H, int W, int R, int S, int stride, int pad, int Kpad,
+                               float* y, void* stream) {
+    ISC_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0);
+    ISC_REQUIRE(Kpad >= R * S * C);
+    if (Kpad % 4 != 0 || !isc_aligned(y, 16)) return ISC_ERR_ALIGNMENT;
+    const int Ho = (H + 2 * pad - R) / stride + 1;
+    const int Wo = (W + 2 * pad - S) / stride + 1;
+    ISC_REQUIRE(Ho > 0 && Wo > 0);
+    const size_t total4 = (size_t)B * Ho * Wo * (Kpad / 4);
+    hipLaunchKernelGGL(k_im2col_nchw, dim3(stream_grid(total4)), dim3(256), 0, isc_stream(stream), x, C, H, W, R, S,
+                       stride, pad, Ho, Wo, Kpad, total4, y);
+    return isc_launch_status();
+}
+
+extern "C" int isc_maxpool_nhwc(const float* x, int B, int H, int W, int C, int R, int stride, int pad, float* y,
+                                void* stream) {
+    ISC_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && R > 0 && stride > 0 && pad >= 0);
+    if (C % 4 != 0) return ISC_ERR_UNSUPPORTED;
+    if (!isc_aligned(x, 16) || !isc_aligned(y, 16)) return ISC_ERR_ALIGNMENT;
+    const int Ho = (H + 2 * pad - R) / stride + 1;
+    const int Wo = (W + 2 * pad - R) / stride + 1;
+    ISC_REQUIRE(Ho > 0 && Wo > 0);
+    const size_t total4 = (size_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(k_maxpool_nhwc, dim3(stream_grid(total4)), dim3(256), 0, isc_stream(stream), x, H, W, C, R, stride,
+                       pad, Ho, Wo, total4, y);
+    return isc_launch_status();
+}
+
+extern "C" int isc_global_avgpool_nhwc(const float* x, int B, int H, int W, int C, float* y, void* stream) {
+    ISC_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0);
+    if (B > 65535) return ISC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_global_avgpool_nhwc, dim3(isc_ceil_div(C, 256), B), dim3(256), 0, isc_stream(stream), x, H * W, C,
+                       y);
+    return isc_launch_status();
+}

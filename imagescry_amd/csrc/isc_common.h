@@ -1,0 +1,49 @@
+// Shared host/device helpers for the gfx950 kernels behind include/imagescry_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/imagescry_hip.h"
+
+#define ISC_WAVE 64
+
+#define ISC_REQUIRE(cond) \
+    do {                  \
+        if (!(cond)) return ISC_ERR_INVALID_ARG; \
+    } while (0)
+
+static inline int isc_launch_status() { return hipGetLastError() == hipSuccess ? ISC_OK : ISC_ERR_LAUNCH; }
+
+static inline hipStream_t isc_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline bool isc_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+template <typename T>
+static inline T isc_ceil_div(T a, T b) {
+    return (a + b - 1) / b;
+}
+
+static inline size_t isc_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- wave-level reductions (64 lanes) ---------------------------------------------------------
+__device__ __forceinline__ float isc_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double isc_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long isc_wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float isc_wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}

@@ -1,0 +1,230 @@
+"""Embedder interface and the ResNet-50 embedder, on MI355X.
+
+`EmbeddingModule` keeps the reference's extension point (src/imagescry/models/embedding.py:27-104): subclasses
+implement `preprocess`, `forward` and `embedding_dim`; `predict_step` runs preprocess -> forward -> L2-normalise
+over channels -> `EmbeddingBatch`; `embed_images` maps it over a dataloader.  The reference gets `.to()` /
+`.device` / the predict loop from Lightning; here they are a few lines of plain Python so that nothing but the
+HIP kernels touches the data.
+"""
+
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from typing import Iterable
+
+import torch
+from torch import Tensor
+
+from imagescry_amd import _lib, resnet50
+from imagescry_amd.data import EmbeddingBatch, ImageBatch
+from imagescry_amd.transforms import normalize_per_channel, resize
+
+__all__ = ["EmbeddingModule", "ResNet50Embedder", "l2_normalize_channels"]
+
+
+def l2_normalize_channels(x: Tensor, eps: float = 1e-12) -> Tensor:
+    """`F.normalize(x, p=2, dim=1)` for a float32 `[B, E, H, W]` map (reference: embedding.py:74)."""
+    if x.ndim != 4 or x.dtype != torch.float32:
+        raise ValueError(f"expected a float32 [B, E, H, W] tensor, got {x.dtype} {tuple(x.shape)}")
+    _lib.require_device(x, "x")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    b, e, h, w = x.shape
+    if x.numel() == 0:
+        return y
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        st = lib.isc_l2norm_channels(x.data_ptr(), b, e, h * w, eps, y.data_ptr(), _lib.stream_handle(x.device))
+    _lib.check(st, "isc_l2norm_channels")
+    return y
+
+
+class EmbeddingModule(ABC):
+    """Embedding module interface (reference: src/imagescry/models/embedding.py:27-104)."""
+
+    def __init__(self) -> None:
+        self._device = torch.device("cpu")
+        self.hparams: dict[str, object] = {}
+
+    # -- subclass contract ---------------------------------------------------------------------------
+    @abstractmethod
+    def preprocess(self, images: Tensor) -> Tensor:
+        """uint8 `[B, C, H1, W1]` -> float `[B, C, H2, W2]` in the format the model expects."""
+
+    @abstractmethod
+    def forward(self, x: Tensor) -> Tensor:
+        """float `[B, C, H1, W1]` -> embedding feature map float `[B, E, H2, W2]`."""
+
+    @property
+    @abstractmethod
+    def embedding_dim(self) -> int:
+        """Embedding dimension E."""
+
+    def _move(self, device: torch.device) -> None:
+        """Move parameters to `device` (subclasses with weights override this)."""
+
+    # -- provided ------------------------------------------------------------------------------------
+    def to(self, device: str | torch.device) -> "EmbeddingModule":
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self._move(device)
+        self._device = device
+        return self
+
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    def __call__(self, x: Tensor) -> Tensor:
+        return self.forward(x)
+
+    def predict_step(self, batch: ImageBatch) -> EmbeddingBatch:
+        """preprocess -> forward -> L2-normalise each embedding vector (reference: embedding.py:57-76)."""
+        if not isinstance(batch, ImageBatch):
+            raise TypeError(f"batch must be an ImageBatch, got {type(batch).__name__}")
+        x = self.preprocess(batch.images)
+        x = self.forward(x)
+        x = l2_normalize_channels(x)
+        return EmbeddingBatch(indices=batch.indices, embeddings=x)
+
+    def embed_images(
+        self,
+        dataloader: Iterable[ImageBatch],
+        *,
+        accelerator: str = "auto",
+        devices: list[int] | str | int = "auto",
+    ) -> list[EmbeddingBatch]:
+        """One `EmbeddingBatch` per input batch, in loader order, `indices` passed through unchanged
+        (reference: embedding.py:78-98, where Lightning's `Trainer.predict` runs the loop).
+
+        `accelerator` must resolve to the GPU ("auto", "gpu", "cuda"); `devices` picks the HIP device of THIS
+        process (an int index, a one-element list, or "auto" = the module's current device).  Whole batches are
+        never split across GPUs -- the normalisation statistics are batch-wide (transforms.py:62-65)."""
+        if accelerator not in ("auto", "gpu", "cuda"):
+            raise ValueError(f"accelerator {accelerator!r} is not available: imagescry_amd runs on HIP devices only")
+        if devices != "auto":
+            ids = [devices] if isinstance(devices, int) else list(devices)
+            if len(ids) != 1:
+                raise ValueError("one process drives one GPU; launch one process per device for more")
+            self.to(torch.device("cuda", int(ids[0])))
+        elif self.device.type != "cuda":
+            self.to(torch.device("cuda", torch.cuda.current_device()))
+        results: list[EmbeddingBatch] = []
+        for batch in dataloader:
+            results.append(self.predict_step(batch.to(self.device)))
+        return results
+
+
+def _conv(x: Tensor, conv: resnet50.FoldedConv, act: int, residual: Tensor | None = None) -> Tensor:
+    """NHWC float32 convolution + bias (+ residual) + activation through `isc_conv2d_nhwc`."""
+    b, h, w, cin = x.shape
+    cout = conv.weight.shape[0]
+    ho = (h + 2 * conv.pad - conv.kernel) // conv.stride + 1
+    wo = (w + 2 * conv.pad - conv.kernel) // conv.stride + 1
+    out = torch.empty((b, ho, wo, cout), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    st = lib.isc_conv2d_nhwc(
+        x.data_ptr(), b, h, w, cin, conv.weight.data_ptr(), cout, conv.kernel, conv.kernel, conv.stride, conv.pad,
+        conv.bias.data_ptr(), _lib.ptr(residual), act, out.data_ptr(), _lib.stream_handle(x.device),
+    )
+    _lib.check(st, "isc_conv2d_nhwc")
+    return out
+
+
+class ResNet50Embedder(EmbeddingModule):
+    """ResNet-50 trunk -> global average pool -> linear projection to `embedding_dim` (BASELINE.json config 2).
+
+    Mirrors the constructor style of the reference's `EfficientNetEmbedder` (embedding.py:111-147): keyword-only
+    arguments, `max_side_length` resize policy, random weights unless a state dict is given.  The output map is
+    `[B, embedding_dim, 1, 1]`, so `get_flat_vectors()` yields one bank row per image.
+    """
+
+    def __init__(
+        self,
+        *,
+        embedding_dim: int = 768,
+        max_side_length: int = 640,
+        state_dict: dict[str, Tensor] | None = None,
+        seed: int = 0,
+    ) -> None:
+        super().__init__()
+        if embedding_dim <= 0 or embedding_dim % 4 != 0:
+            raise ValueError(f"embedding_dim must be a positive multiple of 4, got {embedding_dim}")
+        if max_side_length <= 0:
+            raise ValueError(f"max_side_length must be positive, got {max_side_length}")
+        self._embedding_dim = embedding_dim
+        self.max_side_length = max_side_length
+        self.hparams = {"embedding_dim": embedding_dim, "max_side_length": max_side_length}
+        sd = state_dict if state_dict is not None else resnet50.make_state_dict(embedding_dim=embedding_dim, seed=seed)
+        if sd["fc.weight"].shape[0] != embedding_dim:
+            raise ValueError(f"state dict projects to {sd['fc.weight'].shape[0]} dims, expected {embedding_dim}")
+        self._net = resnet50.fold_state_dict(sd)
+
+    def _move(self, device: torch.device) -> None:
+        self._net = self._net.to(device)
+
+    @property
+    def embedding_dim(self) -> int:
+        return self._embedding_dim
+
+    def preprocess(self, images: Tensor) -> Tensor:
+        """Resize so the long side is at most `max_side_length`, then batch-statistics normalise and clip to
+        [-3, 3] (reference: embedding.py:149-165)."""
+        if not isinstance(images, Tensor) or images.dtype != torch.uint8:
+            raise TypeError("images must be a uint8 tensor")
+        if images.ndim != 4:
+            raise ValueError(f"images must have shape [B, C, H, W], got {tuple(images.shape)}")
+        h, w = images.shape[-2:]
+        if max(h, w) > self.max_side_length:
+            images = resize(images, output_size=self.max_side_length, side_ref="long")
+        return normalize_per_channel(images, min_value=-3, max_value=3)
+
+    def forward(self, x: Tensor) -> Tensor:
+        if not isinstance(x, Tensor) or x.dtype != torch.float32:
+            raise TypeError("x must be a float32 tensor")
+        if x.ndim != 4 or x.shape[1] != 3:
+            raise ValueError(f"x must have shape [B, 3, H, W], got {tuple(x.shape)}")
+        _lib.require_device(x, "x")
+        if self.device != x.device:
+            raise ValueError(f"module is on {self.device} but the input is on {x.device}; call .to() first")
+        x = x.contiguous()
+        b, _c, h, w = x.shape
+        ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+        # the kernels index with 32-bit element offsets: bound the images per pass
+        per_image = max(ho * wo * resnet50.STEM_KPAD, 1)
+        chunk = max(1, min(b, (2**31 - 1) // per_image))
+        out = torch.empty((b, self._embedding_dim), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            for b0 in range(0, b, chunk):
+                out[b0 : b0 + chunk] = self._forward_chunk(x[b0 : b0 + chunk])
+        return out[:, :, None, None]
+
+    def _forward_chunk(self, x: Tensor) -> Tensor:
+        lib = _lib.load()
+        stream = _lib.stream_handle(x.device)
+        net = self._net
+        b, c, h, w = x.shape
+        ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+        kpad = resnet50.STEM_KPAD
+        patches = torch.empty((b, ho, wo, kpad), dtype=torch.float32, device=x.device)
+        _lib.check(lib.isc_im2col_nchw(x.data_ptr(), b, c, h, w, 7, 7, 2, 3, kpad, patches.data_ptr(), stream),
+                   "isc_im2col_nchw")
+        stem = resnet50.FoldedConv(net.stem.weight, net.stem.bias, 1, 1, 0)  # a 1x1 conv over the patch rows
+        y = _conv(patches, stem, _lib.ISC_ACT_RELU)
+        del patches
+        hp, wp = (ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1
+        pooled = torch.empty((b, hp, wp, 64), dtype=torch.float32, device=x.device)
+        _lib.check(lib.isc_maxpool_nhwc(y.data_ptr(), b, ho, wo, 64, 3, 2, 1, pooled.data_ptr(), stream),
+                   "isc_maxpool_nhwc")
+        y = pooled
+        for blk in net.blocks:
+            identity = y if blk.downsample is None else _conv(y, blk.downsample, _lib.ISC_ACT_NONE)
+            t = _conv(y, blk.conv1, _lib.ISC_ACT_RELU)
+            t = _conv(t, blk.conv2, _lib.ISC_ACT_RELU)
+            y = _conv(t, blk.conv3, _lib.ISC_ACT_RELU, residual=identity)
+        bb, hh, ww, cc = y.shape
+        feat = torch.empty((bb, 1, 1, cc), dtype=torch.float32, device=x.device)
+        _lib.check(lib.isc_global_avgpool_nhwc(y.data_ptr(), bb, hh, ww, cc, feat.data_ptr(), stream),
+                   "isc_global_avgpool_nhwc")
+        return _conv(feat, net.fc, _lib.ISC_ACT_NONE).reshape(bb, self._embedding_dim)

@@ -1,0 +1,286 @@
+"""Brute-force cosine top-k over an embedding bank resident in HBM.
+
+The reference stores embeddings as SQLite BLOB rows (src/imagescry/storage/models.py:73-129) and reads them
+back with `get_embeddings_by_image_id` (src/imagescry/storage/operations.py:108-144); it has no search step
+(SURVEY.md section 0 fact 2).  `EmbeddingBank` is the storage-flavoured object BASELINE.json's `north_star`
+asks for: it keeps the `[N, D]` bank on the GPU and answers `search(queries, k)`.
+
+Semantics (pinned by oracle/search_oracle.py, not by the reference):
+`score = float32(dot_f64(q, b) / max(||q||, 1e-12))`, bank rows used as stored (L2-normalised once at build
+time with the `F.normalize` formula of src/imagescry/models/embedding.py:74), results ordered by
+(score descending, row index ascending).  Row ids are positions in the bank, the analogue of the reference's
+DB row order (operations.py:135-144).
+
+Multi-GPU: one process per GPU.  The bank is row-sharded -- rank r holds rows `[r*N//G, (r+1)*N//G)` -- every
+rank searches its shard with the replicated queries, one all-gather (RCCL over xGMI) exchanges the
+`Q x k x 12 B` partial results and every rank merges them; the merge order is total, so the answer does not
+depend on G.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from imagescry_amd import _lib
+from imagescry_amd.data import EmbeddingBatch
+
+__all__ = ["EmbeddingBank", "shard_bounds"]
+
+_PAD_INDEX = torch.iinfo(torch.int64).max
+
+
+def shard_bounds(n_rows: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Contiguous row range `[lo, hi)` of `rank` when `n_rows` are split over `world_size` ranks."""
+    if world_size <= 0 or not 0 <= rank < world_size:
+        raise ValueError(f"invalid rank {rank} for world size {world_size}")
+    return rank * n_rows // world_size, (rank + 1) * n_rows // world_size
+
+
+def _row_multiple(dtype: torch.dtype) -> int:
+    # one K step of the matrix-core kernel is 128 bytes of a row
+    return 64 if dtype == torch.float16 else 32
+
+
+class EmbeddingBank:
+    """`[N, D]` embedding bank on one GPU (or one row shard of it per rank) with cosine top-k search.
+
+    Args:
+        embeddings: floating `[N, D]` tensor on a HIP device.  With `process_group` set and
+            `presharded=False` it is the FULL bank (identical on every rank) and this rank keeps only its
+            rows; with `presharded=True` it is this rank's shard and `index_base` is the global index of
+            its first row.
+        dtype: storage dtype of the bank, `torch.float16` (default) or `torch.float32`.
+        normalize: L2-normalise every row before storing it (skip for rows that are already unit length,
+            e.g. the output of `Embedder.predict_step`; a float16 input with `normalize=False` is used
+            without a copy).
+        index_base: global row index of local row 0 (only with `presharded=True`).
+        process_group: the `torch.distributed` group the bank is sharded over (`None` = single GPU).
+    """
+
+    def __init__(
+        self,
+        embeddings: Tensor,
+        *,
+        dtype: torch.dtype = torch.float16,
+        normalize: bool = True,
+        index_base: int = 0,
+        process_group: dist.ProcessGroup | None = None,
+        presharded: bool = False,
+    ) -> None:
+        if not isinstance(embeddings, Tensor) or not embeddings.dtype.is_floating_point:
+            raise TypeError("embeddings must be a floating point torch.Tensor")
+        if embeddings.ndim != 2:
+            raise ValueError(f"embeddings must have shape [N, D], got {tuple(embeddings.shape)}")
+        if dtype not in (torch.float16, torch.float32):
+            raise ValueError(f"bank dtype must be float16 or float32, got {dtype}")
+        self.process_group = process_group
+        self.world_size = dist.get_world_size(process_group) if process_group is not None else 1
+        self.rank = dist.get_rank(process_group) if process_group is not None else 0
+        if process_group is not None and not presharded:
+            lo, hi = shard_bounds(embeddings.shape[0], self.world_size, self.rank)
+            embeddings = embeddings[lo:hi]
+            index_base = lo
+        elif process_group is None and index_base != 0 and not presharded:
+            raise ValueError("index_base is only meaningful for a presharded bank")
+        self.index_base = int(index_base)
+        self.dtype = dtype
+        self.dim = int(embeddings.shape[1])
+        self.num_local_rows = int(embeddings.shape[0])
+        if self.dim == 0:
+            raise ValueError("embedding dimension must be positive")
+        self._bank = self._store(embeddings, normalize)
+        self._workspaces: dict[tuple[int, int], Tensor] = {}
+        self.last_status: Tensor | None = None
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_batches(cls, batches: Sequence[EmbeddingBatch], **kwargs: object) -> "EmbeddingBank":
+        """Bank whose rows are `get_flat_vectors()` of every batch, in order (reference: data.py:112-118).
+
+        `predict_step` output is already L2-normalised per location, so `normalize` defaults to False here.
+        """
+        if len(batches) == 0:
+            raise ValueError("need at least one EmbeddingBatch")
+        rows = torch.cat([b.get_flat_vectors() for b in batches], dim=0)
+        kwargs.setdefault("normalize", False)
+        return cls(rows, **kwargs)  # type: ignore[arg-type]
+
+    def _store(self, embeddings: Tensor, normalize: bool) -> Tensor:
+        """Row-normalise / cast / zero-pad the rows into the kernel's bank layout (`isc_bank_from_rows`)."""
+        _lib.require_device(embeddings, "embeddings")
+        n, d = embeddings.shape
+        mult = _row_multiple(self.dtype)
+        ld = (d + mult - 1) // mult * mult
+        if not normalize and embeddings.dtype == self.dtype and ld == d and embeddings.is_contiguous():
+            if embeddings.data_ptr() % 16 == 0:
+                return embeddings
+        bank = torch.empty((n, ld), dtype=self.dtype, device=embeddings.device)
+        if n == 0:
+            return bank
+        lib = _lib.load()
+        block = 1 << 20
+        with torch.cuda.device(embeddings.device):
+            for r0 in range(0, n, block):
+                rows = embeddings[r0 : r0 + block].float().contiguous()
+                st = lib.isc_bank_from_rows(
+                    rows.data_ptr(), rows.shape[0], d, rows.stride(0), int(normalize), 1e-12,
+                    bank[r0 : r0 + block].data_ptr(), _lib.dtype_code(self.dtype), ld,
+                    _lib.stream_handle(embeddings.device),
+                )
+                _lib.check(st, "isc_bank_from_rows")
+        return bank
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def device(self) -> torch.device:
+        return self._bank.device
+
+    @property
+    def bank(self) -> Tensor:
+        """The stored `[N_local, D]` rows (a view without the zero padding columns)."""
+        return self._bank[:, : self.dim]
+
+    def __len__(self) -> int:
+        return self.num_local_rows
+
+    # ------------------------------------------------------------------ search
+    def _prepare_queries(self, queries: Tensor) -> Tensor:
+        if not isinstance(queries, Tensor) or not queries.dtype.is_floating_point:
+            raise TypeError("queries must be a floating point torch.Tensor")
+        if queries.ndim != 2 or queries.shape[1] != self.dim:
+            raise ValueError(f"queries must have shape [Q, {self.dim}], got {tuple(queries.shape)}")
+        if queries.device != self.device:
+            raise ValueError(f"queries are on {queries.device} but the bank is on {self.device}")
+        ld = self._bank.shape[1]
+        q = queries.to(self.dtype)
+        if ld != self.dim:
+            q = torch.nn.functional.pad(q, (0, ld - self.dim))
+        q = q.contiguous()
+        if q.data_ptr() % 16 != 0:  # pragma: no cover - torch allocations are 256-byte aligned
+            q = q.clone()
+        return q
+
+    def _workspace(self, n_queries: int, k: int) -> Tensor:
+        key = (n_queries, k)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            lib = _lib.load()
+            need = _lib.c_size_t()
+            st = lib.isc_cosine_topk_workspace_bytes(
+                _lib.dtype_code(self.dtype), self.num_local_rows, self._bank.shape[1], n_queries, k, need
+            )
+            _lib.check(st, "isc_cosine_topk_workspace_bytes")
+            ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+            self._workspaces = {key: ws}  # keep one: the workspace can be > 100 MiB
+        return ws
+
+    def _local_topk(self, queries: Tensor, k: int, check: bool) -> tuple[Tensor, Tensor]:
+        """Top-k of this rank's rows: `(float32 [Q, k], int64 [Q, k])` with GLOBAL row indices."""
+        nq = queries.shape[0]
+        scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        indices = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        status = torch.empty(4, dtype=torch.int32, device=self.device)
+        ws = self._workspace(nq, k)
+        lib = _lib.load()
+        code = _lib.dtype_code(self.dtype)
+        args = (
+            self._bank.data_ptr(), code, self.num_local_rows, self._bank.shape[1], self._bank.stride(0),
+            queries.data_ptr(), nq, queries.stride(0), k, self.index_base, scores.data_ptr(), indices.data_ptr(),
+        )
+        with torch.cuda.device(self.device):
+            stream = _lib.stream_handle(self.device)
+            st = lib.isc_cosine_topk(*args, status.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+            _lib.check(st, "isc_cosine_topk")
+            self.last_status = status
+            if check and int(status[0].item()) != 0:
+                # a candidate buffer overflowed (adversarially ordered or heavily duplicated bank):
+                # redo this call with the data-independent float64 kernel
+                need = _lib.c_size_t()
+                _lib.check(
+                    lib.isc_cosine_topk_exhaustive_workspace_bytes(
+                        code, self.num_local_rows, self._bank.shape[1], nq, k, need
+                    ),
+                    "isc_cosine_topk_exhaustive_workspace_bytes",
+                )
+                ews = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+                st = lib.isc_cosine_topk_exhaustive(*args, ews.data_ptr(), ews.numel(), stream)
+                _lib.check(st, "isc_cosine_topk_exhaustive")
+        return scores, indices
+
+    def _merge_topk(self, scores: Tensor, indices: Tensor, k: int) -> tuple[Tensor, Tensor]:
+        """Merge `[G, Q, kin]` partial results into `[Q, k]` by (score desc, index asc) (`isc_topk_merge`)."""
+        g, nq, kin = scores.shape
+        out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+        out_i = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
+        lib = _lib.load()
+        with torch.cuda.device(scores.device):
+            st = lib.isc_topk_merge(
+                scores.contiguous().data_ptr(), indices.contiguous().data_ptr(), g, nq, kin, k, out_s.data_ptr(),
+                out_i.data_ptr(), _lib.stream_handle(scores.device),
+            )
+        _lib.check(st, "isc_topk_merge")
+        return out_s, out_i
+
+    def _total_rows(self) -> int:
+        if self.process_group is None:
+            return self.num_local_rows
+        counts = [0] * self.world_size
+        dist.all_gather_object(counts, self.num_local_rows, group=self.process_group)
+        return int(sum(counts))
+
+    def search(self, queries: Tensor, k: int = 10, *, check: bool = True) -> tuple[Tensor, Tensor]:
+        """Cosine top-k of every query against the whole (possibly sharded) bank.
+
+        Returns `(scores float32 [Q, k], indices int64 [Q, k])`, best first, ties by lower row index.
+        With `check=False` the overflow status word is not read back (no host synchronisation); inspect
+        `last_status[0]` later -- non-zero means the call has to be repeated with `check=True`.
+        """
+        if not isinstance(k, int) or isinstance(k, bool):
+            raise TypeError(f"k must be an int, got {type(k).__name__}")
+        if k < 1:
+            raise ValueError(f"k must be >= 1, got {k}")
+        if k > _lib.ISC_TOPK_MAX_K:
+            raise ValueError(f"k must be <= {_lib.ISC_TOPK_MAX_K}, got {k}")
+        q = self._prepare_queries(queries)
+        nq = q.shape[0]
+        if self.process_group is None:
+            if k > self.num_local_rows:
+                raise ValueError(f"k={k} exceeds the bank size {self.num_local_rows}")
+            if nq == 0:
+                return (torch.empty((0, k), dtype=torch.float32, device=self.device),
+                        torch.empty((0, k), dtype=torch.int64, device=self.device))
+            return self._local_topk(q, k, check)
+
+        # ---- sharded: local partial top-k -> one all-gather -> merge on every rank
+        if not hasattr(self, "_n_total"):
+            self._n_total = self._total_rows()
+        if k > self._n_total:
+            raise ValueError(f"k={k} exceeds the bank size {self._n_total}")
+        kl = min(k, self.num_local_rows)
+        part_s = torch.full((nq, k), -math.inf, dtype=torch.float32, device=self.device)
+        part_i = torch.full((nq, k), _PAD_INDEX, dtype=torch.int64, device=self.device)
+        if kl > 0 and nq > 0:
+            s, i = self._local_topk(q, kl, check)
+            part_s[:, :kl] = s
+            part_i[:, :kl] = i
+        all_s, all_i = self._all_gather_partials(part_s, part_i)
+        if nq == 0:
+            return part_s, part_i
+        return self._merge_topk(all_s, all_i, k)
+
+    def _all_gather_partials(self, part_s: Tensor, part_i: Tensor) -> tuple[Tensor, Tensor]:
+        """One collective for both arrays: the float32 scores travel bit-cast inside an int64 `[Q, k, 2]` buffer."""
+        nq, k = part_s.shape
+        packed = torch.empty((nq, k, 2), dtype=torch.int64, device=part_s.device)
+        packed[..., 0] = part_s.view(torch.int32).to(torch.int64)
+        packed[..., 1] = part_i
+        gathered = torch.empty((self.world_size, nq, k, 2), dtype=torch.int64, device=part_s.device)
+        dist.all_gather_into_tensor(gathered, packed, group=self.process_group)
+        all_s = gathered[..., 0].to(torch.int32).view(torch.float32)
+        all_i = gathered[..., 1].contiguous()
+        return all_s.contiguous(), all_i

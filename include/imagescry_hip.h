@@ -1,0 +1,167 @@
+/*
+ * imagescry_hip.h -- C ABI of the MI355X (gfx950) embed-and-search hot path.
+ *
+ * This is the drop-in boundary.  The reference
+ * (libertininick/imagescry) is pure Python and has no FFI; each entry point below
+ * names the reference Python function whose arithmetic it replaces.  The Python
+ * surface in `imagescry_amd/` (same class / function names as the reference) binds
+ * these symbols through ctypes -- see INTEGRATION.md for the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless a parameter says
+ *     "host"; nothing is allocated or freed inside the library;
+ *   - `stream` is a `hipStream_t` passed as `void*` (NULL = the default stream); all
+ *     work is enqueued on it and the call returns without synchronising, so the
+ *     functions may be captured into a hipGraph;
+ *   - scratch memory is a caller-provided workspace whose size is queried first;
+ *   - return value: 0 = ISC_OK, negative = error (see `isc_strerror`); never throws;
+ *   - layouts are row-major / NCHW or NHWC as stated per function, dense unless a
+ *     leading dimension is given (in ELEMENTS).
+ */
+#ifndef IMAGESCRY_HIP_H
+#define IMAGESCRY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISC_ABI_VERSION 1
+
+/* element types */
+#define ISC_U8 0
+#define ISC_F16 1
+#define ISC_F32 2
+
+/* status codes */
+#define ISC_OK 0
+#define ISC_ERR_INVALID_ARG (-1)  /* NULL pointer, non-positive size, bad enum        */
+#define ISC_ERR_UNSUPPORTED (-2)  /* valid request this build has no kernel for        */
+#define ISC_ERR_WORKSPACE (-3)    /* workspace missing or smaller than the queried size */
+#define ISC_ERR_LAUNCH (-4)       /* hipGetLastError() != hipSuccess after a launch    */
+#define ISC_ERR_NO_DEVICE (-5)    /* no HIP device / wrong architecture                */
+#define ISC_ERR_ALIGNMENT (-6)    /* pointer or leading dimension not aligned as required */
+
+/* activation selector for the encoder blocks */
+#define ISC_ACT_NONE 0
+#define ISC_ACT_RELU 1
+#define ISC_ACT_GELU 2 /* exact erf form */
+
+int isc_abi_version(void);
+const char* isc_strerror(int status);
+/* device properties the host side sizes launches with; any out pointer may be NULL (host pointers) */
+int isc_device_info(int* num_cus, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
+
+/* ---------------------------------------------------------------------------------------------
+ * Preprocess
+ * ------------------------------------------------------------------------------------------- */
+
+/* Batch-wide per-channel mean and UNBIASED standard deviation of an NCHW image batch.
+ * Replaces `image_tensor.mean(dim=(0,2,3))` / `.std(dim=(0,2,3))` in
+ * reference src/imagescry/image/transforms.py:62-65.
+ *   x            [B,C,H,W] of `dtype` (ISC_U8 or ISC_F32), contiguous
+ *   mean, stdev  float [C] outputs
+ * u8 input is accumulated exactly (integer sums of x and x*x), f32 input in float64. */
+int isc_channel_stats_workspace_bytes(int dtype, int B, int C, int H, int W, size_t* bytes);
+int isc_channel_stats(const void* x, int dtype, int B, int C, int H, int W, float* mean, float* stdev,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* y = clip((float(x) - mean[c]) / (stdev[c] + eps), lo, hi).  Pass -INFINITY / +INFINITY to disable a bound.
+ * Replaces reference src/imagescry/image/transforms.py:58-72.
+ *   mean/stdev are float arrays of `stat_batch`*C values with stat_batch in {1, B}
+ *   (the reference's `#B C 1 1` broadcast rule, transforms.py:19-20). */
+int isc_normalize_clip(const void* x, int dtype, int B, int C, int H, int W, const float* mean, const float* stdev,
+                       int stat_batch, float eps, float lo, float hi, float* y, void* stream);
+
+/* Bilinear resize, align_corners=False, no antialias; the input is cast to float first.
+ * Replaces `interpolate(image.float(), ..., mode="bilinear", align_corners=False)` in
+ * reference src/imagescry/image/transforms.py:103-121.  Source coordinate
+ * (dst + 0.5) * (in / out) - 0.5 clamped at 0, as torch's upsample_bilinear2d.
+ *   x [planes,H1,W1] of `dtype` (ISC_U8 or ISC_F32); y float [planes,H2,W2]; planes = B*C. */
+int isc_resize_bilinear(const void* x, int dtype, int planes, int H1, int W1, int H2, int W2, float* y, void* stream);
+
+/* y[b,:,s] = x[b,:,s] / max(||x[b,:,s]||_2, eps) for x float [B,E,S] (S = H*W; channel dimension normalised).
+ * Replaces `nn.functional.normalize(x, p=2, dim=1)` in reference src/imagescry/models/embedding.py:74. */
+int isc_l2norm_channels(const float* x, int B, int E, int S, float eps, float* y, void* stream);
+
+/* Row-wise L2 normalisation of a [N,D] float matrix (leading dimension ldx) into a bank of `out_dtype`
+ * (ISC_F16 or ISC_F32, leading dimension ldy >= D; columns D..ldy-1 are zero-filled).  Same formula as above;
+ * used once when an embedding bank is built from `EmbeddingBatch.get_flat_vectors()` rows
+ * (reference src/imagescry/data.py:112-118). */
+int isc_bank_from_rows(const float* x, int64_t N, int D, int64_t ldx, int normalize, float eps, void* y,
+                       int out_dtype, int64_t ldy, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder blocks (float32, NHWC activations, KRSC weights)
+ * ------------------------------------------------------------------------------------------- */
+
+/* NCHW float -> NHWC float repack ([B,C,H,W] -> [B,H,W,Cpad], channels C..Cpad-1 zero). */
+int isc_nchw_to_nhwc(const float* x, int B, int C, int H, int W, int Cpad, float* y, void* stream);
+
+/* out = act(conv2d(x, w) + bias [+ residual]) as an implicit GEMM on the f32 matrix cores.
+ * The build's stand-in for the torchvision backbone the reference calls at
+ * src/imagescry/models/embedding.py:167-177 (BatchNorm folded into w / bias by the host).
+ *   x        float [B,H,W,Cin]         NHWC, Cin % 32 == 0... see ISC_ERR_UNSUPPORTED
+ *   w        float [Cout,R,S,Cin]      KRSC
+ *   bias     float [Cout] or NULL
+ *   residual float [B,Ho,Wo,Cout] or NULL (added before the activation)
+ *   out      float [B,Ho,Wo,Cout],  Ho = (H + 2*pad - R)/stride + 1 (same for Wo)
+ * A linear layer is the case H=W=R=S=1. */
+int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S, int stride,
+                    int pad, const float* bias, const float* residual, int act, float* out, void* stream);
+
+/* im2col for the stem convolution (small Cin): x NCHW float [B,C,H,W] -> patches float [B*Ho*Wo, Kpad] with the K axis
+ * ordered (r, s, c) and zero-padded from R*S*C to Kpad. */
+int isc_im2col_nchw(const float* x, int B, int C, int H, int W, int R, int S, int stride, int pad, int Kpad, float* y,
+                    void* stream);
+
+/* max pooling, NHWC float, window R x R, -inf padding (torch.nn.functional.max_pool2d semantics). */
+int isc_maxpool_nhwc(const float* x, int B, int H, int W, int C, int R, int stride, int pad, float* y, void* stream);
+
+/* global average pooling, NHWC float [B,H,W,C] -> [B,C]. */
+int isc_global_avgpool_nhwc(const float* x, int B, int H, int W, int C, float* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Search
+ * ------------------------------------------------------------------------------------------- */
+
+/* Brute-force cosine top-k of `Q` queries against `N` bank rows.
+ * No reference symbol exists; semantics are the oracle's
+ * (oracle/search_oracle.py): score = float32(dot_f64(q,b) / max(||q||_2,1e-12)), bank rows used as
+ * stored, result ordered by (score descending, row index ascending).
+ *   bank         [N, D] of `dtype` (ISC_F16 or ISC_F32), leading dimension ldb (elements, % 8 == 0 for f16 / % 4 for f32,
+ *                base pointer 16-byte aligned); D % 64 == 0 (f16) or % 32 == 0 (f32) -- pad with zero columns
+ *   queries      [Q, D] of the SAME dtype, leading dimension ldq, same alignment rules
+ *   k            1 <= k <= min(N, ISC_TOPK_MAX_K)
+ *   index_base   added to every returned row index (global index of this shard's row 0)
+ *   out_scores   float   [Q, k]
+ *   out_indices  int64_t [Q, k]
+ *   status       int32_t [4] device words, written by the kernels:
+ *                  [0] = number of (segment, query) candidate buffers that overflowed (result then INVALID --
+ *                        the host must rerun with isc_cosine_topk_exhaustive), [1..3] reserved
+ */
+#define ISC_TOPK_MAX_K 120
+int isc_cosine_topk_workspace_bytes(int dtype, int64_t N, int D, int Q, int k, size_t* bytes);
+int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, int64_t ldb, const void* queries, int Q, int64_t ldq,
+                    int k, int64_t index_base, float* out_scores, int64_t* out_indices, int32_t* status,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same contract, data-independent cost: every score is evaluated in float64 and kept in a per-query list.
+ * Slow (vector FMA, no matrix cores); the fallback for inputs whose candidate buffers overflow. */
+int isc_cosine_topk_exhaustive_workspace_bytes(int dtype, int64_t N, int D, int Q, int k, size_t* bytes);
+int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N, int D, int64_t ldb, const void* queries, int Q,
+                               int64_t ldq, int k, int64_t index_base, float* out_scores, int64_t* out_indices,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* Merge G partial results (e.g. one per bank shard after the all-gather) into the final top-k by
+ * (score descending, index ascending): scores float [G,Q,kin], indices int64 [G,Q,kin] -> [Q,kout], kout <= G*kin <= 4096. */
+int isc_topk_merge(const float* scores, const int64_t* indices, int G, int Q, int kin, int kout, float* out_scores,
+                   int64_t* out_indices, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMAGESCRY_HIP_H */

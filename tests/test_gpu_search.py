@@ -1,0 +1,215 @@
+"""GPU parity of `EmbeddingBank.search` (C ABI: isc_cosine_topk / isc_topk_merge / isc_cosine_topk_exhaustive).
+
+Bar: top-k indices bit-exact against the oracle's total order (score desc, index asc);
+scores are the float32 rounding of a float64 evaluation on both sides, compared to 1e-6 -- well inside the
+1e-5 (fp32) / 1e-2 (fp16) tolerance `north_star` states.
+"""
+
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
+import cases  # noqa: E402
+
+from oracle import search_oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+SCORE_ATOL = 1e-6
+GOLDEN = np.load(Path(__file__).resolve().parent / "golden" / "search.npz")
+
+
+def _bank(bank: torch.Tensor, device: torch.device, **kw):
+    from imagescry_amd import EmbeddingBank
+
+    return EmbeddingBank(bank.to(device), dtype=bank.dtype, normalize=False, **kw)
+
+
+def _check(scores: torch.Tensor, indices: torch.Tensor, exp_s: np.ndarray, exp_i: np.ndarray) -> None:
+    assert indices.dtype == torch.int64 and scores.dtype == torch.float32
+    np.testing.assert_array_equal(indices.cpu().numpy(), exp_i)
+    np.testing.assert_allclose(scores.cpu().numpy(), exp_s, rtol=0, atol=SCORE_ATOL)
+
+
+@pytest.mark.parametrize("name", list(cases.SEARCH_CASES))
+def test_search_matches_golden(name: str, device: torch.device) -> None:
+    n, d, q, k, dtype = cases.SEARCH_CASES[name]
+    bank, queries = cases.search_case(n, d, q, dtype)
+    scores, indices = _bank(bank, device).search(queries.to(device), k)
+    _check(scores, indices, GOLDEN[f"{name}_scores"], GOLDEN[f"{name}_indices"])
+
+
+@pytest.mark.parametrize("dtype,tag", [(torch.float16, "f16"), (torch.float32, "f32")])
+def test_exact_ties_go_to_the_lowest_index(dtype: torch.dtype, tag: str, device: torch.device) -> None:
+    bank, queries = cases.tie_case(dtype)
+    scores, indices = _bank(bank, device).search(queries.to(device), 50)
+    _check(scores, indices, GOLDEN[f"tie_{tag}_scores"], GOLDEN[f"tie_{tag}_indices"])
+    # query 0 is 3 * base[0]: its 40 exact copies (rows 0, 24, 48, ...) lead, in index order
+    assert indices[0, :40].cpu().tolist() == list(range(0, 24 * 40, 24))
+
+
+@pytest.mark.parametrize(
+    "n,d,q,k,dtype",
+    [
+        (256, 768, 256, 10, torch.float32),  # BASELINE config 0 shape: 256 embeddings searched against themselves
+        (257, 64, 1, 1, torch.float16),  # one query, k = 1, ragged bank
+        (4097, 128, 5, 120, torch.float16),  # largest k, one row past the first level
+        (266241, 64, 9, 10, torch.float16),  # three levels (4096 | 262144 | rest)
+        (70000, 768, 300, 10, torch.float16),  # two query tiles
+        (9000, 1536, 17, 10, torch.float32),
+    ],
+)
+def test_search_matches_oracle(n: int, d: int, q: int, k: int, dtype: torch.dtype, device: torch.device) -> None:
+    bank, queries = cases.search_case(n, d, q, dtype, seed=n + q)
+    exp_s, exp_i = search_oracle.cosine_topk(bank, queries, k)
+    scores, indices = _bank(bank, device).search(queries.to(device), k)
+    _check(scores, indices, exp_s, exp_i)
+
+
+def test_self_search_config0(device: torch.device) -> None:
+    """BASELINE config 0: every embedding finds itself at rank 0 with score 1 +- 1e-5."""
+    bank, _ = cases.search_case(256, 768, 1, torch.float32)
+    eb = _bank(bank, device)
+    scores, indices = eb.search(bank.to(device), 10)
+    assert indices[:, 0].cpu().tolist() == list(range(256))
+    assert torch.allclose(scores[:, 0].cpu(), torch.ones(256), atol=1e-5)
+
+
+def test_zero_query_and_unpadded_dim(device: torch.device) -> None:
+    """A zero query scores 0 against every row -> rows 0..k-1; D = 100 is zero-padded to the kernel's K step."""
+    bank, queries = cases.search_case(1000, 100, 4, torch.float16)
+    queries[1] = 0
+    exp_s, exp_i = search_oracle.cosine_topk(bank, queries, 8)
+    from imagescry_amd import EmbeddingBank
+
+    eb = EmbeddingBank(bank.to(device), dtype=torch.float16, normalize=False)
+    scores, indices = eb.search(queries.to(device), 8)
+    _check(scores, indices, exp_s, exp_i)
+    assert indices[1].cpu().tolist() == list(range(8))
+    assert scores[1].abs().max().item() == 0.0
+
+
+def test_bank_normalisation_and_fp32_queries(device: torch.device) -> None:
+    """`normalize=True` applies the F.normalize formula before the cast; float32 queries are cast to the bank dtype."""
+    g = cases.gen(5)
+    raw = torch.randn(3000, 192, generator=g) * 4.0
+    queries = torch.randn(6, 192, generator=g)
+    from imagescry_amd import EmbeddingBank
+
+    eb = EmbeddingBank(raw.to(device), dtype=torch.float16, normalize=True)
+    stored = eb.bank.cpu()
+    expect = search_oracle.l2_normalize_rows(raw).half()
+    assert (stored.float() - expect.float()).abs().max().item() <= 2.0 ** -11  # at most one fp16 ulp below 1.0
+    exp_s, exp_i = search_oracle.cosine_topk(stored, queries.half(), 10)
+    scores, indices = eb.search(queries.to(device), 10)
+    _check(scores, indices, exp_s, exp_i)
+
+
+def test_index_base_and_merge_equal_unsharded(device: torch.device) -> None:
+    """Searching 4 row shards with their index_base and merging equals the unsharded search (G-independence)."""
+    bank, queries = cases.search_case(10000, 256, 20, torch.float16, seed=3)
+    k = 10
+    exp_s, exp_i = search_oracle.cosine_topk(bank, queries, k)
+    from imagescry_amd import EmbeddingBank, shard_bounds
+
+    parts_s, parts_i = [], []
+    for r in range(4):
+        lo, hi = shard_bounds(10000, 4, r)
+        eb = EmbeddingBank(bank[lo:hi].to(device), dtype=torch.float16, normalize=False, index_base=lo, presharded=True)
+        s, i = eb.search(queries.to(device), k)
+        parts_s.append(s)
+        parts_i.append(i)
+    ms, mi = eb._merge_topk(torch.stack(parts_s), torch.stack(parts_i), k)
+    _check(ms, mi, exp_s, exp_i)
+
+
+def test_exhaustive_kernel_matches_oracle(device: torch.device) -> None:
+    from imagescry_amd import _lib
+
+    for dtype in (torch.float16, torch.float32):
+        bank, queries = cases.search_case(5000, 160, 11, dtype, seed=9)
+        k = 10
+        exp_s, exp_i = search_oracle.cosine_topk(bank, queries, k, index_base=1000)
+        b, q = bank.to(device), queries.to(device)
+        lib = _lib.load()
+        need = _lib.c_size_t()
+        code = _lib.dtype_code(dtype)
+        _lib.check(lib.isc_cosine_topk_exhaustive_workspace_bytes(code, 5000, 160, 11, k, need), "ws")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+        s = torch.empty((11, k), dtype=torch.float32, device=device)
+        i = torch.empty((11, k), dtype=torch.int64, device=device)
+        st = lib.isc_cosine_topk_exhaustive(
+            b.data_ptr(), code, 5000, 160, 160, q.data_ptr(), 11, 160, k, 1000, s.data_ptr(), i.data_ptr(),
+            ws.data_ptr(), ws.numel(), _lib.stream_handle(device),
+        )
+        _lib.check(st, "isc_cosine_topk_exhaustive")
+        _check(s, i, exp_s, exp_i)
+
+
+def test_overflow_falls_back_to_exhaustive(device: torch.device) -> None:
+    """A bank sorted by ascending similarity to the query makes every later row beat the threshold: the
+    candidate buffers overflow, status[0] becomes non-zero and `search` reruns on the exhaustive kernel."""
+    d = 64
+    g = cases.gen(11)
+    q = torch.nn.functional.normalize(torch.randn(1, d, generator=g), dim=1)
+    noise = torch.nn.functional.normalize(torch.randn(40000, d, generator=g), dim=1)
+    t = torch.linspace(0.0, 0.9, 40000)[:, None]
+    bank = torch.nn.functional.normalize(t * q + (1 - t) * noise * 0.2, dim=1).half()
+    queries = q.half()
+    exp_s, exp_i = search_oracle.cosine_topk(bank, queries, 10)
+    eb = _bank(bank, device)
+    scores, indices = eb.search(queries.to(device), 10)
+    _check(scores, indices, exp_s, exp_i)
+
+
+def test_argument_errors(device: torch.device) -> None:
+    bank, queries = cases.search_case(300, 64, 2, torch.float16)
+    eb = _bank(bank, device)
+    with pytest.raises(ValueError):
+        eb.search(queries.to(device), 301)
+    with pytest.raises(ValueError):
+        eb.search(queries.to(device), 0)
+    with pytest.raises(ValueError):
+        eb.search(queries[:, :32].to(device), 5)
+    with pytest.raises(TypeError):
+        eb.search(queries.to(device).to(torch.int32), 5)
+    with pytest.raises(ValueError):
+        eb.search(queries, 5)  # CPU queries against a GPU bank
+
+
+@pytest.mark.parametrize("dtype", [torch.float16])
+def test_full_size_properties(dtype: torch.dtype, device: torch.device) -> None:
+    """BASELINE config 3 shape (1M x 768, 1024 queries, k = 10) checked without a CPU oracle:
+    the expected answer is rebuilt on the GPU with torch float64 matmuls (test-side only)."""
+    n, d, q, k = 1_000_000, 768, 1024, 10
+    g = torch.Generator(device=device).manual_seed(1234)
+    bank = torch.nn.functional.normalize(torch.randn(n, d, generator=g, device=device), dim=1).to(dtype)
+    queries = torch.randn(q, d, generator=g, device=device).to(dtype)
+    from imagescry_amd import EmbeddingBank
+
+    eb = EmbeddingBank(bank, dtype=dtype, normalize=False)
+    scores, indices = eb.search(queries, k)
+    assert int(eb.last_status[0].item()) == 0
+    # sortedness under the total order
+    s, i = scores.double(), indices
+    assert bool(((s[:, :-1] > s[:, 1:]) | ((s[:, :-1] == s[:, 1:]) & (i[:, :-1] < i[:, 1:]))).all())
+    # returned scores are the exact cosine of the returned rows
+    q64 = queries.double()
+    denom = q64.norm(dim=1).clamp_min(1e-12)
+    rows = bank[indices.reshape(-1)].double().reshape(q, k, d)
+    exact = (torch.einsum("qkd,qd->qk", rows, q64) / denom[:, None]).float()
+    assert torch.allclose(scores, exact, rtol=0, atol=1e-7)
+    # nothing outside the returned set beats the k-th score
+    kth = scores[:, -1].double()
+    better = torch.zeros(q, dtype=torch.int64, device=device)
+    for r0 in range(0, n, 65536):
+        blk = (q64 @ bank[r0 : r0 + 65536].double().T / denom[:, None]).float().double()
+        better += (blk > kth[:, None]).sum(dim=1)
+    assert bool((better <= k - 1).all())
+    assert bool((better == (scores.double() > kth[:, None]).sum(dim=1)).all())
