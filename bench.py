@@ -1,0 +1,335 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the embed-and-search hot path on MI355X (contract: see the build prompt / DESIGN.md).
+
+    python bench.py --gpus N --steps K --warmup W            # N = 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                 # N > 1, one rank per GPU over RCCL
+
+Primary workload (`--workload search`, BASELINE.json config 3/4): cosine top-10 of 1024 fp16 queries against a
+10,000,000 x 768 fp16 bank.  STRONG scaling: the bank is fixed and row-sharded over the N ranks (rank r
+generates rows [r*N/G, (r+1)*N/G) on its device, seed 1234 + r); a step is one `EmbeddingBank.search` call --
+local MFMA filter + exact re-score, one RCCL all-gather of the Q x k partials, merge.  `value` = queries/s.
+
+Secondary (reported in the same JSON line under "encode", rank 0's GPU only): ResNet-50 -> 768-d float32
+`predict_step` on 512 random 224 x 224 uint8 images (BASELINE.json config 2), images/s.
+
+`--workload encode` makes the encode the primary metric instead (replicas: every rank encodes its own batch of
+512, weak scaling, no collective).
+
+Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from imagescry_amd import EmbeddingBank, ImageBatch, ResNet50Embedder, _lib, resnet50, shard_bounds  # noqa: E402
+
+SEED = 1234
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16
+MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA == vector rate
+
+
+def parse_args() -> argparse.Namespace:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["search", "encode"], default="search")
+    ap.add_argument("--bank-rows", type=int, default=10_000_000, help="total bank rows (all ranks together)")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--queries", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=512, help="encode batch (images per step per rank)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    return ap.parse_args()
+
+
+def setup_dist(args: argparse.Namespace) -> tuple[int, int, torch.device]:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    return rank, world, device
+
+
+def fence(world: int) -> None:
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds: float, world: int, device: torch.device) -> float:
+    if world == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def timed_steps(step, steps: int, warmup: int, world: int, device: torch.device) -> float:
+    """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize; max over ranks, seconds."""
+    for _ in range(warmup):
+        step()
+    fence(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence(world)
+    return max_over_ranks(time.perf_counter() - t0, world, device)
+
+
+# ------------------------------------------------------------------------------------------------ search
+def make_shard(lo: int, hi: int, dim: int, device: torch.device, seed: int) -> torch.Tensor:
+    """Random unit-norm fp16 rows generated on the device in 1M-row blocks (SURVEY.md section 8d input 4)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = torch.empty((hi - lo, dim), dtype=torch.float16, device=device)
+    for r0 in range(0, hi - lo, 1 << 20):
+        blk = torch.randn((min(1 << 20, hi - lo - r0), dim), generator=g, device=device)
+        out[r0 : r0 + blk.shape[0]] = torch.nn.functional.normalize(blk, dim=1).half()
+    return out
+
+
+def bench_search(args: argparse.Namespace, rank: int, world: int, device: torch.device) -> dict:
+    n, d, q, k = args.bank_rows, args.dim, args.queries, args.k
+    lo, hi = shard_bounds(n, world, rank)
+    shard = make_shard(lo, hi, d, device, SEED + rank)
+    queries = torch.randn((q, d), generator=torch.Generator().manual_seed(SEED)).half().to(device)
+    group = dist.group.WORLD if world > 1 else None
+    bank = EmbeddingBank(shard, dtype=torch.float16, normalize=False, index_base=lo, process_group=group,
+                         presharded=True)
+
+    def step() -> None:
+        bank.search(queries, k)
+
+    for _ in range(args.warmup):
+        step()
+    _lib.timing_enable(True)
+    _lib.timing_read(_lib.ISC_KERNEL_DOTS_FILTER)
+    seconds = timed_steps(step, args.steps, 0, world, device)
+    kernel_ms, launches = _lib.timing_read(_lib.ISC_KERNEL_DOTS_FILTER)
+    _lib.timing_enable(False)
+    overflow = int(bank.last_status[0].item())
+
+    # algorithmic work of the dominant kernel (k_dots_filter), summed over its launches of one step on this rank:
+    # every local bank row is read once and dotted with every query
+    rows = hi - lo
+    flops_per_step = 2.0 * q * rows * d
+    bytes_per_step = rows * d * 2.0 + q * d * 2.0 + q * k * 12.0
+    kernel_s_per_step = kernel_ms / 1e3 / args.steps
+    launches_per_step = launches / args.steps
+    tflops = flops_per_step / kernel_s_per_step / 1e12
+    gbs = bytes_per_step / kernel_s_per_step / 1e9
+    # arithmetic intensity ~ q flop/byte (fp16 bank): the MFMA roofline binds above ~310 queries, HBM below
+    ridge = MFMA_F16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    bound = "mfma" if flops_per_step / bytes_per_step >= ridge else "hbm"
+    roofline = {
+        "kernel": "k_dots_filter<f16>",
+        "bound": bound,
+        "achieved": round(tflops if bound == "mfma" else gbs, 2),
+        "peak": MFMA_F16_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
+        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+        "frac": round((tflops / MFMA_F16_PEAK_TFLOPS) if bound == "mfma" else (gbs / HBM_PEAK_GBS), 4),
+        "traffic": None,
+        "launches_per_step": launches_per_step,
+        "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
+        "kernel_ms_per_step": round(kernel_s_per_step * 1e3, 4),
+        "algorithmic_flops_per_step": flops_per_step,
+        "algorithmic_bytes_per_step": bytes_per_step,
+        "mfma_frac": round(tflops / MFMA_F16_PEAK_TFLOPS, 4),
+        "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+    }
+    return {
+        "metric": "queries/s cosine top-10 over N x D bank",
+        "value": round(q * args.steps / seconds, 1),
+        "unit": "queries/s",
+        "ms_per_step": round(seconds / args.steps * 1e3, 4),
+        "scaling": "strong",
+        "dtype": "f16",
+        "config": {
+            "workload": f"cosine top-{k}: {q} fp16 queries x {n} x {d} fp16 bank (BASELINE config 4 bank; "
+                        f"row-sharded {world} way{'s' if world > 1 else ''})",
+            "bank_rows": n, "dim": d, "queries": q, "k": k, "rows_per_gpu": rows,
+            "parallelism": f"row-shard{world}" + ("+allgather" if world > 1 else ""),
+        },
+        "roofline": roofline,
+        "overflowed_candidate_buffers": overflow,
+        "_bank": bank, "_queries": queries,
+    }
+
+
+def cpu_baseline_search(args: argparse.Namespace) -> dict:
+    """The oracle's float32 torch expression on the host cores, on a bounded row sample of the same workload."""
+    from oracle import search_oracle
+
+    sample_rows = min(args.bank_rows, 1_000_000)
+    g = torch.Generator().manual_seed(SEED)
+    bank = torch.nn.functional.normalize(torch.randn((sample_rows, args.dim), generator=g), dim=1)
+    queries = torch.randn((args.queries, args.dim), generator=torch.Generator().manual_seed(SEED)).half().float()
+    cores = torch.get_num_threads()
+    search_oracle.cosine_topk_torch_blocked(bank[: sample_rows // 8], queries, args.k)  # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while reps < 2 or (time.perf_counter() - t0 < 8.0 and reps < 10):
+        search_oracle.cosine_topk_torch_blocked(bank, queries, args.k)
+        reps += 1
+    per_pass = (time.perf_counter() - t0) / reps
+    scaled = per_pass * args.bank_rows / sample_rows  # cost is linear in the bank rows
+    return {
+        "value": round(args.queries / scaled, 2),
+        "unit": "queries/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"oracle.search_oracle.cosine_topk_torch_blocked (float32 GEMM + topk), {args.queries} queries x "
+                  f"{sample_rows} of the {args.bank_rows} rows, {reps} passes of {per_pass:.2f} s, scaled linearly "
+                  f"to the full bank",
+        "gflops": round(2.0 * args.queries * sample_rows * args.dim / per_pass / 1e9, 1),
+    }
+
+
+# ------------------------------------------------------------------------------------------------ encode
+def bench_encode(args: argparse.Namespace, rank: int, world: int, device: torch.device, steps: int, warmup: int,
+                 collective_timing: bool) -> dict:
+    b = args.batch
+    model = ResNet50Embedder(seed=0).to(device)
+    images = torch.randint(0, 256, (b, 3, 224, 224), dtype=torch.uint8,
+                           generator=torch.Generator().manual_seed(SEED + rank)).to(device)
+    batch = ImageBatch(indices=torch.arange(b, device=device), images=images)
+
+    def step() -> None:
+        model.predict_step(batch)
+
+    for _ in range(warmup):
+        step()
+    _lib.timing_enable(True)
+    _lib.timing_read(_lib.ISC_KERNEL_CONV)
+    seconds = timed_steps(step, steps, 0, world if collective_timing else 1, device)
+    kernel_ms, launches = _lib.timing_read(_lib.ISC_KERNEL_CONV)
+    _lib.timing_enable(False)
+    flops = float(resnet50.conv_flops(b, 224, 224))
+    tflops = flops * steps / (kernel_ms / 1e3) / 1e12
+    ranks = world if collective_timing else 1
+    return {
+        "metric": "images/s encode",
+        "value": round(b * ranks * steps / seconds, 1),
+        "unit": "images/s",
+        "ms_per_step": round(seconds / steps * 1e3, 3),
+        "scaling": "weak",
+        "dtype": "f32",
+        "config": {"workload": f"ResNet-50 (random weights) batch-{b} 224x224 uint8 -> 768-d predict_step, fp32 "
+                               f"(BASELINE config 2)", "batch_per_gpu": b, "parallelism": f"replicas{ranks}"},
+        "roofline": {
+            "kernel": "k_conv_f32",
+            "bound": "mfma",
+            "achieved": round(tflops, 2),
+            "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "launches_per_step": launches / steps,
+            "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
+            "kernel_ms_per_step": round(kernel_ms / steps, 3),
+            "algorithmic_flops_per_step": flops,
+        },
+        "_model": model, "_images": images,
+    }
+
+
+def cpu_baseline_encode(args: argparse.Namespace) -> dict:
+    from oracle import encoder_oracle
+
+    sample = 16
+    sd = resnet50.make_state_dict(seed=0)
+    images = torch.randint(0, 256, (sample, 3, 224, 224), dtype=torch.uint8,
+                           generator=torch.Generator().manual_seed(SEED))
+    encoder_oracle.predict_step_embeddings(images[:2], sd)
+    reps, t0 = 0, time.perf_counter()
+    while reps < 1 or (time.perf_counter() - t0 < 6.0 and reps < 8):
+        encoder_oracle.predict_step_embeddings(images, sd)
+        reps += 1
+    per_pass = (time.perf_counter() - t0) / reps
+    return {
+        "value": round(sample / per_pass, 2),
+        "unit": "images/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"oracle.encoder_oracle.predict_step_embeddings (torch CPU float32), batch of {sample} of the "
+                  f"{args.batch} images, {reps} passes of {per_pass:.2f} s (batch statistics are per sample batch)",
+    }
+
+
+def strip(d: dict) -> dict:
+    return {k: v for k, v in d.items() if not k.startswith("_")}
+
+
+def main() -> None:
+    args = parse_args()
+    rank, world, device = setup_dist(args)
+    torch.manual_seed(SEED)
+    if args.workload == "search":
+        primary = bench_search(args, rank, world, device)
+        primary.pop("_bank"), primary.pop("_queries")
+        torch.cuda.empty_cache()
+        secondary = None
+        if not args.no_secondary and rank == 0:
+            secondary = bench_encode(args, rank, world, device, steps=3, warmup=1, collective_timing=False)
+    else:
+        primary = bench_encode(args, rank, world, device, args.steps, args.warmup, collective_timing=True)
+        secondary = None
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        line = {
+            "metric": primary["metric"],
+            "value": primary["value"],
+            "unit": primary["unit"],
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": primary["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": primary["scaling"],
+            "vs_baseline": None,  # the reference publishes no number for this metric
+            "dtype": primary["dtype"],
+            "data": "synthetic (seeded random unit-norm bank / random uint8 images, random-init weights)",
+            "config": primary["config"],
+            "roofline": primary["roofline"],
+        }
+        if "overflowed_candidate_buffers" in primary:
+            line["overflowed_candidate_buffers"] = primary["overflowed_candidate_buffers"]
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_search(args) if args.workload == "search" else cpu_baseline_encode(args)
+        if secondary is not None:
+            enc = strip(secondary)
+            if world == 1 and not args.no_cpu_baseline:
+                enc["cpu_baseline"] = cpu_baseline_encode(args)
+            line["encode"] = enc
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

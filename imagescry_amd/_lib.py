@@ -9,7 +9,6 @@ from __future__ import annotations
 
 import ctypes
 import math
-import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 from pathlib import Path
 
@@ -21,6 +20,7 @@ LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
 ISC_U8, ISC_F16, ISC_F32 = 0, 1, 2
 ISC_ACT_NONE, ISC_ACT_RELU, ISC_ACT_GELU = 0, 1, 2
 ISC_TOPK_MAX_K = 120
+ISC_KERNEL_DOTS_FILTER, ISC_KERNEL_CONV = 0, 1
 
 ISC_OK = 0
 ISC_ERR_INVALID_ARG = -1
@@ -40,6 +40,8 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "isc_abi_version": (c_int, []),
     "isc_strerror": (c_char_p, [c_int]),
     "isc_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "isc_timing_enable": (c_int, [c_int]),
+    "isc_timing_read": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
     "isc_channel_stats_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "isc_channel_stats": (
         c_int,
@@ -101,10 +103,6 @@ def load() -> ctypes.CDLL:
     except OSError as exc:  # pragma: no cover - depends on the host's ROCm install
         raise HipLibraryError(f"could not load {LIB_PATH}: {exc}") from exc
     missing = [name for name in SIGNATURES if not hasattr(lib, name)]
-    if missing and os.environ.get("ISC_PARTIAL_LIB") == "1":  # bring-up only: bind what exists
-        missing_now, missing = missing, []
-        for name in missing_now:
-            SIGNATURES.pop(name)
     if missing:
         raise HipLibraryError(f"{LIB_PATH} does not export {missing}; rebuild it with `python -m imagescry_amd.build`")
     for name, (restype, argtypes) in SIGNATURES.items():
@@ -158,3 +156,15 @@ def dtype_code(dtype: torch.dtype) -> int:
 
 
 INF = math.inf
+
+
+def timing_enable(enable: bool) -> None:
+    check(load().isc_timing_enable(int(enable)), "isc_timing_enable")
+
+
+def timing_read(kernel_id: int) -> tuple[float, int]:
+    """(summed device milliseconds, launches) of one instrumented kernel since the last read."""
+    total = ctypes.c_double()
+    n = c_int()
+    check(load().isc_timing_read(kernel_id, total, n), "isc_timing_read")
+    return total.value, n.value

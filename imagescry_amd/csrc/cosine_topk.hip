@@ -519,9 +519,11 @@ int run(const void* bank, int64_t n, int d, int64_t ldb, const void* queries, in
                        status);
     for (int level = 0;; ++level) {
         const Level l = make_level(level, n, p.qtiles);
+        isc_timing_begin(ISC_KERNEL_DOTS_FILTER, stream);
         hipLaunchKernelGGL(k_dots_filter<T>, dim3(l.nchunks, p.qtiles), dim3(NTHREADS), 0, stream,
                            static_cast<const T*>(bank), ldb, n, l.r0, l.r1, l.tiles_per_chunk, l.ntiles,
                            static_cast<const T*>(queries), ldq, q, ksteps, w.tau, p.qpad, w.seg_cnt, w.seg_ent, status);
+        isc_timing_end(ISC_KERNEL_DOTS_FILTER, stream);
         hipLaunchKernelGGL(k_select, dim3(q), dim3(256), 0, stream, w.seg_cnt, w.seg_ent, 2 * l.nchunks, p.qpad, p.kp,
                            w.tau, w.carry_s, w.carry_r, w.carry_n, status);
         if (l.r1 >= n) break;

@@ -57,8 +57,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
     const int wave = tid >> 6;
     const int wco = wave % WCO;
     const int wpix = wave / WCO;
-    const int co0 = blockIdx.x * TCO;
-    const int pix0 = blockIdx.y * TPIX;
+    // 1-D grid, output-channel tile fastest: the workgroups that re-read one pixel tile run back to back
+    const int n_co_tiles = (p.Cout + TCO - 1) / TCO;
+    const int co0 = (int)(blockIdx.x % n_co_tiles) * TCO;
+    const int pix0 = (int)(blockIdx.x / n_co_tiles) * TPIX;
 
     // ---- staging assignment: slot = tid + 256 * i  ->  row (tid >> 3) + 32 * i, physical chunk tid & 7
     const int srow = tid >> 3;
@@ -289,14 +291,16 @@ extern "C" int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, con
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = Cin / 32; p.ksteps = R * S * (Cin / 32); p.act = act;
     hipStream_t s = isc_stream(stream);
-    if (Cout <= 64) {
-        const dim3 grid(isc_ceil_div(Cout, 64), (unsigned)isc_ceil_div<int64_t>(M, 256));
-        if (grid.y > 65535u * 16u) return ISC_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((k_conv_f32<64, 256>), grid, dim3(256), 0, s, p);
-    } else {
-        const dim3 grid(isc_ceil_div(Cout, 128), (unsigned)isc_ceil_div<int64_t>(M, 128));
-        hipLaunchKernelGGL((k_conv_f32<128, 128>), grid, dim3(256), 0, s, p);
-    }
+    const bool narrow = Cout <= 64;
+    const int64_t blocks = narrow ? isc_ceil_div(Cout, 64) * isc_ceil_div<int64_t>(M, 256)
+                                  : isc_ceil_div(Cout, 128) * isc_ceil_div<int64_t>(M, 128);
+    if (blocks > 0x7fffffff) return ISC_ERR_UNSUPPORTED;
+    isc_timing_begin(ISC_KERNEL_CONV, s);
+    if (narrow)
+        hipLaunchKernelGGL((k_conv_f32<64, 256>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((k_conv_f32<128, 128>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    isc_timing_end(ISC_KERNEL_CONV, s);
     return isc_launch_status();
 }
 

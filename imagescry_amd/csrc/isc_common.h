@@ -19,6 +19,10 @@ static inline hipStream_t isc_stream(void* s) { return reinterpret_cast<hipStrea
 
 static inline bool isc_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// device-time bracket around one kernel launch (no-ops unless isc_timing_enable(1); defined in capi.hip)
+void isc_timing_begin(int kernel_id, hipStream_t stream);
+void isc_timing_end(int kernel_id, hipStream_t stream);
+
 template <typename T>
 static inline T isc_ceil_div(T a, T b) {
     return (a + b - 1) / b;

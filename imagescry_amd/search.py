@@ -279,8 +279,10 @@ class EmbeddingBank:
         packed = torch.empty((nq, k, 2), dtype=torch.int64, device=part_s.device)
         packed[..., 0] = part_s.view(torch.int32).to(torch.int64)
         packed[..., 1] = part_i
-        gathered = torch.empty((self.world_size, nq, k, 2), dtype=torch.int64, device=part_s.device)
+        # rank-major concatenation along dim 0 (the form both RCCL and gloo accept), viewed as [G, Q, k, 2]
+        gathered = torch.empty((self.world_size * nq, k, 2), dtype=torch.int64, device=part_s.device)
         dist.all_gather_into_tensor(gathered, packed, group=self.process_group)
+        gathered = gathered.view(self.world_size, nq, k, 2)
         all_s = gathered[..., 0].to(torch.int32).view(torch.float32)
         all_i = gathered[..., 1].contiguous()
         return all_s.contiguous(), all_i

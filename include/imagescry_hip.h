@@ -55,6 +55,15 @@ const char* isc_strerror(int status);
 /* device properties the host side sizes launches with; any out pointer may be NULL (host pointers) */
 int isc_device_info(int* num_cus, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
 
+/* Per-kernel device timing for the roofline line of bench.py.  While enabled, every launch of the kernels
+ * below is bracketed by hipEvents recorded on the caller's stream; `isc_timing_read` synchronises those events,
+ * returns the summed device time and the launch count since the last read, and clears them (host pointers). */
+#define ISC_KERNEL_DOTS_FILTER 0 /* k_dots_filter: the MFMA score + threshold-filter pass of isc_cosine_topk */
+#define ISC_KERNEL_CONV 1        /* k_conv_f32: the implicit-GEMM convolution of isc_conv2d_nhwc */
+#define ISC_KERNEL_COUNT 2
+int isc_timing_enable(int enable);
+int isc_timing_read(int kernel_id, double* total_ms, int* launches);
+
 /* ---------------------------------------------------------------------------------------------
  * Preprocess
  * ------------------------------------------------------------------------------------------- */
