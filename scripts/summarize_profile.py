@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ directory (scripts/profile_gpu.sh) into profiles/<tag>_summary.json.
+
+HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are reported in units of 1024 B; on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide (16 B / lane) coalesced streaming read, so the read side
+is doubled for the streaming kernels; WRITE_SIZE is exact.
+"""
+from __future__ import annotations
+
+import collections
+import csv
+import glob
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+tag = sys.argv[1]
+src = ROOT / "gpurun_out" / f"prof_{tag}"
+out = ROOT / "profiles" / f"{tag}_summary.json"
+KERNELS = ("k_dots_filter", "k_conv_f32", "k_select", "k_rescore", "k_im2col", "k_topk_merge", "k_maxpool")
+
+
+def short(name: str) -> str | None:
+    for k in KERNELS:
+        if k in name:
+            if k == "k_conv_f32":
+                return "k_conv_f32<64,256>" if ("64, 256" in name or "Li64ELi256" in name) else "k_conv_f32<128,128>"
+            return k
+    return None
+
+
+summary: dict = {"tag": tag, "kernel_stats": {}, "pmc_per_launch": {}}
+stats = glob.glob(str(src / "stats/*/*kernel_stats.csv"))
+if stats:
+    for r in csv.DictReader(open(stats[0])):
+        k = short(r["Name"])
+        if k:
+            summary["kernel_stats"][k] = {
+                "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2),
+                "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 3), "pct": float(r["Percentage"]),
+                "max_us": round(float(r["MaxNs"]) / 1e3, 2),
+            }
+    (ROOT / "profiles" / f"{tag}_kernel_stats.csv").write_text(open(stats[0]).read())
+for sub in ("pmc_fetch", "pmc_write", "pmc_mfma"):
+    files = glob.glob(str(src / sub / "*/*counter_collection.csv"))
+    if not files:
+        continue
+    agg: dict = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(files[0])):
+        k = short(r["Kernel_Name"])
+        if k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, counters in agg.items():
+        for c, vals in counters.items():
+            entry = summary["pmc_per_launch"].setdefault(k, {})
+            entry[c] = {"launches": len(vals), "max": max(vals), "mean": sum(vals) / len(vals)}
+# derived numbers for the search kernel: the largest launch of a step is the level that streams the bank
+d = summary["pmc_per_launch"].get("k_dots_filter", {})
+if "FETCH_SIZE" in d:
+    big = {
+        "hbm_read_bytes_corrected": d["FETCH_SIZE"]["max"] * 1024 * 2,
+        "hbm_write_bytes": d.get("WRITE_SIZE", {}).get("max", 0) * 1024,
+        "hbm_read_bytes_all_launches_of_a_step_corrected": d["FETCH_SIZE"]["mean"] * 3 * 1024 * 2,
+    }
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
+        busy = d["SQ_VALU_MFMA_BUSY_CYCLES"]["max"] / 1024.0  # per SIMD (256 CUs x 4)
+        active = d["GRBM_GUI_ACTIVE"]["max"] / 8.0  # per XCD
+        big["mfma_busy_frac"] = round(busy / active, 4)
+    summary["k_dots_filter_largest_launch"] = big
+out.write_text(json.dumps(summary, indent=1))
+print(json.dumps(summary, indent=1))
