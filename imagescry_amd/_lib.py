@@ -54,10 +54,12 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     ),
     "isc_resize_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isc_l2norm_channels": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
-    "isc_bank_from_rows": (
+    "isc_bank_packed_bytes": (c_int, [c_int, c_int64, c_int, POINTER(c_size_t)]),
+    "isc_bank_pack": (
         c_int,
-        [c_void_p, c_int64, c_int, c_int64, c_int, c_float, c_void_p, c_int, c_int64, c_void_p],
+        [c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_int, c_float, c_void_p, c_int, c_void_p],
     ),
+    "isc_bank_unpack": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "isc_nchw_to_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isc_conv2d_nhwc": (
         c_int,
@@ -73,13 +75,13 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "isc_cosine_topk_workspace_bytes": (c_int, [c_int, c_int64, c_int, c_int, c_int, POINTER(c_size_t)]),
     "isc_cosine_topk": (
         c_int,
-        [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p,
+        [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p,
          c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     "isc_cosine_topk_exhaustive_workspace_bytes": (c_int, [c_int, c_int64, c_int, c_int, c_int, POINTER(c_size_t)]),
     "isc_cosine_topk_exhaustive": (
         c_int,
-        [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p,
+        [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p,
          c_void_p, c_size_t, c_void_p],
     ),
     "isc_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -15,11 +15,16 @@
 // The matrix-core pass only has to be a superset filter; ordering and the returned scores come from the exact
 // pass, so the result does not depend on tile shape, accumulation order, chunking or sharding.
 //
-// Data layout.  Bank and queries are row-major [rows][ld] with K (the embedding axis) contiguous -- both MFMA
-// operands are "K-major", so the same staging code serves A (bank rows, the streamed operand) and B (queries).
-// One K step is 128 bytes of every row (64 halves or 32 floats).  LDS tiles are [256 rows][128 B], the eight
-// 16-byte chunks of a row XOR-swizzled with (row >> 1) & 7 so that a ds_read_b128 of an MFMA fragment
-// (16 rows x 4 chunks per wave) is bank-conflict free; the image is lane-linear in the staging order.
+// Data layout.  The bank is PACKED (bank_layout.h): [tile of 256 rows][K step][row][128 B], so the block one K
+// step of one tile needs is 32 KiB of contiguous HBM and a workgroup's whole chunk is one linear stream.  The
+// queries are packed the same way per call (1.5 MiB, L2 resident).  Both MFMA operands are "K-major", so the same
+// staging code serves A (bank rows, the streamed operand) and B (queries).  One K step is 128 bytes of every row
+// (64 halves or 32 floats).  LDS tiles are [256 rows][128 B], the eight 16-byte chunks of a row XOR-swizzled with
+// (row >> 1) & 7 so that a ds_read_b128 of an MFMA fragment (16 rows x 4 chunks per wave) is bank-conflict free;
+// the LDS image is lane-linear in the staging order (the swizzle is applied to the LDS-DMA source address).
+#include <stdlib.h>
+
+#include "bank_layout.h"
 #include "isc_common.h"
 
 namespace {
@@ -30,13 +35,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int TM = 256;        // bank rows per tile
 constexpr int TN = 256;        // queries per tile
 constexpr int NTHREADS = 512;  // 8 waves: 2 along the bank rows x 4 along the queries, 128 x 64 outputs each
-constexpr int CAP = 128;       // candidate slots per (segment, query)
+constexpr int CAP = 32;        // candidate slots per (segment, query); a segment = (chunk, row-half wave, lane group)
 constexpr int64_t LEVEL0_ROWS = 4096;
 constexpr int LEVEL_RATIO = 64;
 constexpr int TARGET_WGS = 256;  // one workgroup per MI355X CU (the kernel needs 130 KiB of LDS)
 constexpr int MAX_CHUNKS = 256;
 constexpr int SELECT_CAP = 8192;  // candidates one k_select workgroup can hold in LDS
 constexpr int SLACK = 6;
+constexpr int SEGS_PER_CHUNK = 8;  // 2 row-half waves x 4 lane groups, each with private survivor counters
 
 struct Cand {
     float s;
@@ -47,7 +53,7 @@ struct Plan {
     int kp;       // candidates carried per query (>= k + SLACK, multiple of 16)
     int qtiles;   // ceil(Q / 256)
     int qpad;     // qtiles * 256
-    int max_seg;  // 2 * max chunks over the levels
+    int max_seg;  // SEGS_PER_CHUNK * max chunks over the levels
 };
 
 struct Level {
@@ -88,7 +94,7 @@ Plan make_plan(int64_t n, int q, int k) {
     p.max_seg = 0;
     for (int level = 0;; ++level) {
         const Level l = make_level(level, n, p.qtiles);
-        if (2 * l.nchunks > p.max_seg) p.max_seg = 2 * l.nchunks;
+        if (SEGS_PER_CHUNK * l.nchunks > p.max_seg) p.max_seg = SEGS_PER_CHUNK * l.nchunks;
         if (l.r1 >= n) break;
     }
     return p;
@@ -101,10 +107,11 @@ struct Workspace {
     int32_t* carry_n;  // [qpad]
     int32_t* seg_cnt;  // [max_seg][qpad]
     Cand* seg_ent;     // [max_seg][qpad][CAP]
+    unsigned char* qpacked;  // [qtiles][ks][256][128 B]
     size_t bytes;
 };
 
-Workspace carve(const Plan& p, void* base) {
+Workspace carve(const Plan& p, int ks, void* base) {
     Workspace w;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -118,6 +125,7 @@ Workspace carve(const Plan& p, void* base) {
     w.carry_n = static_cast<int32_t*>(take((size_t)p.qpad * 4));
     w.seg_cnt = static_cast<int32_t*>(take((size_t)p.max_seg * p.qpad * 4));
     w.seg_ent = static_cast<Cand*>(take((size_t)p.max_seg * p.qpad * CAP * sizeof(Cand)));
+    w.qpacked = static_cast<unsigned char*>(take((size_t)p.qtiles * ks * ISC_TILE_KSTEP_BYTES));
     w.bytes = off;
     return w;
 }
@@ -131,20 +139,49 @@ __global__ void k_init(float* tau, int32_t* carry_n, int q, int qpad, int32_t* s
     if (i < 4) status[i] = 0;
 }
 
+// queries row-major [q][ldq] -> packed [qtile][K step][256][128 B]; rows >= q and columns >= d are zero.
+// One thread per 16-byte chunk.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_queries(const T* __restrict__ queries, int64_t ldq, int q, int d, int ks,
+                                                      int qpad, unsigned char* __restrict__ packed) {
+    constexpr int PER = 16 / (int)sizeof(T);
+    const int total = qpad * ks * 8;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = i & 7;
+    const int row = (i >> 3) % ISC_TILE_ROWS;
+    const int blk = (i >> 3) / ISC_TILE_ROWS;  // qtile * ks + kstep
+    const int kstep = blk % ks;
+    const int qrow = (blk / ks) * ISC_TILE_ROWS + row;
+    T v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int e = (kstep * 8 + c) * PER + j;
+        v[j] = (qrow < q && e < d) ? queries[(int64_t)qrow * ldq + e] : (T)0.f;
+    }
+    *reinterpret_cast<uint4*>(packed + (size_t)i * 16) = *reinterpret_cast<const uint4*>(v);
+}
+
 // --- operand traits -------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 template <typename T>
 struct Mma;
 
 template <>
 struct Mma<_Float16> {
-    // one 16-byte chunk = 8 halves = the k-slice one lane feeds to v_mfma_f32_16x16x32_f16
-    static __device__ __forceinline__ void run(const uint4 (&a)[8], const uint4 (&b)[4], f32x4 (&acc)[8][4]) {
+    // acc[n] += A(16 rows) . B(16 queries x n) over the 64 halves of one K step.  One 16-byte chunk = 8 halves = the
+    // k-slice one lane feeds to v_mfma_f32_16x16x32_f16; a0/b[0] hold chunks 0-3, a1/b[1] chunks 4-7.
+    static __device__ __forceinline__ void row(const u32x4& a0, const u32x4& a1, const u32x4 (&b)[2][4],
+                                               f32x4 (&acc)[4]) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
+        for (int n = 0; n < 4; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a0),
+                                                            __builtin_bit_cast(half8, b[0][n]), acc[n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a[m]),
-                                                                   __builtin_bit_cast(half8, b[n]), acc[m][n], 0, 0, 0);
+        for (int n = 0; n < 4; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a1),
+                                                            __builtin_bit_cast(half8, b[1][n]), acc[n], 0, 0, 0);
     }
 };
 
@@ -153,35 +190,57 @@ struct Mma<float> {
     // one 16-byte chunk = 4 floats: element j of every lane's chunk goes to the j-th v_mfma_f32_16x16x4_f32.
     // Lane group g therefore supplies k = 4 * chunk + j instead of k = g: a permutation of the K axis applied
     // identically to both operands, which leaves the dot products unchanged.
-    static __device__ __forceinline__ void run(const uint4 (&a)[8], const uint4 (&b)[4], f32x4 (&acc)[8][4]) {
+    static __device__ __forceinline__ void row(const u32x4& a0, const u32x4& a1, const u32x4 (&b)[2][4],
+                                               f32x4 (&acc)[4]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
+            for (int n = 0; n < 4; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a0[j]), __uint_as_float(b[0][n][j]),
+                                                              acc[n], 0, 0, 0);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const unsigned au = j == 0 ? a[m].x : j == 1 ? a[m].y : j == 2 ? a[m].z : a[m].w;
-                    const unsigned bu = j == 0 ? b[n].x : j == 1 ? b[n].y : j == 2 ? b[n].z : b[n].w;
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(au), __uint_as_float(bu),
-                                                                     acc[m][n], 0, 0, 0);
-                }
+            for (int n = 0; n < 4; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a1[j]), __uint_as_float(b[1][n][j]),
+                                                              acc[n], 0, 0, 0);
+        }
     }
 };
 
-// LDS map: [A0 | A1 | B0 | B1] 32 KiB each, then the per-wave survivor counters.
-constexpr int TILE_BYTES = TM * 128;
-constexpr int LDS_CNT_OFF = 4 * TILE_BYTES;
-constexpr int LDS_BYTES = LDS_CNT_OFF + 8 * 64 * 4;
+// LDS fragment read, hidden from the compiler: a C++ load from the staging array would make hipcc drain the
+// in-flight LDS-DMA (s_waitcnt vmcnt(0)) in front of it.  The destination is valid only after the counted
+// lgkmcnt wait that names it.
+#define ISC_DS_READ(dst_, addr_, off_) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_))
 
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_dots_filter(const T* __restrict__ bank, int64_t ldb, int64_t n_rows,
-                                                          int64_t r0, int64_t r1, int tiles_per_chunk, int ntiles,
-                                                          const T* __restrict__ queries, int64_t ldq, int n_queries,
-                                                          int ksteps, const float* __restrict__ tau, int qpad,
+// LDS map: a 3-deep ring of bank tiles (A) and a 2-deep ring of query tiles (B), 32 KiB each: exactly 160 KiB.
+constexpr int TILE_BYTES = TM * 128;
+constexpr int A_STAGES = 3;
+constexpr int B_STAGES = 2;
+constexpr int LDS_BYTES = (A_STAGES + B_STAGES) * TILE_BYTES;
+
+// Direct global -> LDS copy (LDS-DMA): lane l of the wave writes 16 bytes at lds_wave_base + 16 * l.
+__device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// One workgroup = one 256-query tile x one chunk of consecutive 256-row bank tiles.
+//
+// Pipeline: K steps of all the chunk's tiles form one stream.  Iteration k issues the LDS-DMA of query step
+// k + 1 and bank step k + 2, computes step k, then waits with a COUNTED vmcnt (the bank step issued last stays
+// in flight) and a raw s_barrier -- two K steps (~4096 MFMA cycles) of HBM latency are covered without holding a
+// single staging register.  Ordering rules (cdna_hip_programming.md, "Pipelining across barriers"): a slot is
+// read one iteration after the vmcnt + barrier that retires its DMA, and refilled one barrier after its last read.
+// DBG is a bring-up aid (ISC_DEBUG_MODE environment variable, never set in production): 1 = query tile staged only
+// once per chunk, 2 = no staging at all after the prologue, 3 = staging but no MFMAs, 4 / 5 = like 3 with only the bank / only the query stream (drained every step).  Results are wrong for != 0.
+template <typename T, int DBG>
+__global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* __restrict__ bank, int64_t r0,
+                                                          int64_t r1, int tiles_per_chunk, int ntiles,
+                                                          const unsigned char* __restrict__ qpacked, int ksteps,
+                                                          const float* __restrict__ tau, int qpad,
                                                           int32_t* __restrict__ seg_cnt, Cand* __restrict__ seg_ent,
                                                           int32_t* __restrict__ status) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-    int* cnt_all = reinterpret_cast<int*>(lds + LDS_CNT_OFF);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];  // the ONLY LDS object (see the guide)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -192,31 +251,47 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const T* __restrict__ 
     const int qt = blockIdx.y;
     const int q0 = qt * TN;
 
-    int* cnt = cnt_all + wave * 64;
-    cnt[lane] = 0;
-
     const int tile_begin = chunk * tiles_per_chunk;
     const int tile_end = min(ntiles, tile_begin + tiles_per_chunk);
     const int my_tiles = tile_end - tile_begin;
 
-    // thresholds of this lane's four query columns
+    // thresholds of this lane's four query columns, and this lane's private survivor counters
     float thr[4];
+    int cnt[4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) thr[n] = tau[q0 + wn * 64 + n * 16 + (lane & 15)];
+    for (int n = 0; n < 4; ++n) {
+        thr[n] = tau[q0 + wn * 64 + n * 16 + (lane & 15)];
+        cnt[n] = 0;
+    }
 
-    // --- staging assignment: slot p = tid + 512 * i  ->  row p >> 3, physical chunk p & 7
-    const int srow = tid >> 3;  // + 64 * i
+    // --- staging: the K-step block of a tile is 32 KiB contiguous in memory ([row][128 B]); staging round i moves
+    // slots p = tid + 512 * i (row p >> 3, 16-byte chunk p & 7) so that every wave instruction reads and writes one
+    // contiguous KiB.  The LDS image is lane-linear; the XOR swizzle is applied to the SOURCE chunk index.
+    const int srow = tid >> 3;
     const int spc = tid & 7;
-    const unsigned char* bbase = reinterpret_cast<const unsigned char*>(bank);
-    const unsigned char* qbase = reinterpret_cast<const unsigned char*>(queries);
-    const int64_t ldb_bytes = ldb * (int64_t)sizeof(T);
-    const int64_t ldq_bytes = ldq * (int64_t)sizeof(T);
+    const int slot_src = srow * 128 + ((spc ^ ((srow >> 1) & 7)) << 4);  // (srow + 64 i) >> 1: same low bits for all i
+    // chunk of this workgroup: tiles are consecutive, so (tile, K step) -> one linear stream of 32 KiB blocks
+    const unsigned char* a_stream = bank + ((r0 >> 8) + tile_begin) * (int64_t)ksteps * ISC_TILE_KSTEP_BYTES + slot_src;
+    const unsigned char* b_stream = qpacked + (int64_t)qt * ksteps * ISC_TILE_KSTEP_BYTES + slot_src;
 
-    const int aoff = (spc ^ ((srow >> 1) & 7)) * 16;  // (row + 64 i) >> 1 has the same low three bits
-    // query rows of this tile never change: precompute their byte offsets (clamped to the last valid query)
-#define ISC_QOFF(i_) \
-    ((int64_t)min(q0 + srow + 64 * (i_), n_queries - 1) * ldq_bytes + ((spc ^ (((srow + 64 * (i_)) >> 1) & 7)) * 16))
-    const int64_t qoff0 = ISC_QOFF(0), qoff1 = ISC_QOFF(1), qoff2 = ISC_QOFF(2), qoff3 = ISC_QOFF(3);
+    unsigned char* const lds_a = lds;
+    unsigned char* const lds_b = lds + A_STAGES * TILE_BYTES;
+    const unsigned lds_a_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned lds_b_addr = lds_a_addr + A_STAGES * TILE_BYTES;
+    const int wave_dst = wave * 1024;  // + 8192 * i: this wave's 1 KiB piece of staging round i
+
+    auto issue_a = [&](int step) {
+        const unsigned char* src = a_stream + (int64_t)step * ISC_TILE_KSTEP_BYTES;
+        unsigned char* dst = lds_a + (step % A_STAGES) * TILE_BYTES + wave_dst;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(src + 8192 * i, dst + 8192 * i);
+    };
+    auto issue_b = [&](int step) {
+        const unsigned char* src = b_stream + (int64_t)(step % ksteps) * ISC_TILE_KSTEP_BYTES;
+        unsigned char* dst = lds_b + (step & 1) * TILE_BYTES + wave_dst;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(src + 8192 * i, dst + 8192 * i);
+    };
 
     // --- fragment read offsets (bytes inside a tile image)
     const int frow = lane & 15;
@@ -235,64 +310,72 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const T* __restrict__ 
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int total_steps = my_tiles * ksteps;
-    uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;  // named registers: an array here ends up in scratch
+    const int seg = (chunk * 2 + wm) * 4 + fg;
+    Cand* my_ent = seg_ent + ((size_t)seg * qpad + q0 + wn * 64 + frow) * CAP;  // + n * 16 * CAP
 
-#define ISC_LOAD_ONE(i_, sa_, sb_)                                                                           \
-    {                                                                                                        \
-        int64_t grow_ = trow0_ + srow + 64 * (i_);                                                           \
-        if (grow_ > n_rows - 1) grow_ = n_rows - 1;                                                          \
-        sa_ = *reinterpret_cast<const uint4*>(bbase + grow_ * ldb_bytes + (int64_t)kt_ * 128 + aoff);        \
-        sb_ = *reinterpret_cast<const uint4*>(qbase + qoff##i_ + (int64_t)kt_ * 128);                        \
-    }
-#define ISC_LOAD_STEP(step_)                                           \
-    do {                                                               \
-        const int t_ = (step_) / ksteps;                               \
-        const int kt_ = (step_) - t_ * ksteps;                         \
-        const int64_t trow0_ = r0 + (int64_t)(tile_begin + t_) * TM;   \
-        ISC_LOAD_ONE(0, sa0, sb0)                                      \
-        ISC_LOAD_ONE(1, sa1, sb1)                                      \
-        ISC_LOAD_ONE(2, sa2, sb2)                                      \
-        ISC_LOAD_ONE(3, sa3, sb3)                                      \
-    } while (0)
-#define ISC_STORE_STEP(buf_)                                                  \
-    do {                                                                      \
-        unsigned char* a_ = lds + (buf_) * TILE_BYTES + tid * 16;             \
-        unsigned char* b_ = lds + (2 + (buf_)) * TILE_BYTES + tid * 16;       \
-        *reinterpret_cast<uint4*>(a_) = sa0;                                  \
-        *reinterpret_cast<uint4*>(a_ + NTHREADS * 16) = sa1;                  \
-        *reinterpret_cast<uint4*>(a_ + NTHREADS * 32) = sa2;                  \
-        *reinterpret_cast<uint4*>(a_ + NTHREADS * 48) = sa3;                  \
-        *reinterpret_cast<uint4*>(b_) = sb0;                                  \
-        *reinterpret_cast<uint4*>(b_ + NTHREADS * 16) = sb1;                  \
-        *reinterpret_cast<uint4*>(b_ + NTHREADS * 32) = sb2;                  \
-        *reinterpret_cast<uint4*>(b_ + NTHREADS * 48) = sb3;                  \
-    } while (0)
-
-    const int seg = chunk * 2 + wm;
-    Cand* my_ent = seg_ent + ((size_t)seg * qpad + q0 + wn * 64) * CAP;
-
+    // prologue: B(0), A(0), A(1) in this order, so that a vmcnt(4) leaves exactly A(1) in flight
     if (total_steps > 0) {
-        ISC_LOAD_STEP(0);
-        ISC_STORE_STEP(0);
+        issue_b(0);
+        issue_a(0);
+        if (total_steps > 1) {
+            issue_a(1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
 
     int kt = 0, tile = 0;
     for (int step = 0; step < total_steps; ++step) {
-        const int buf = step & 1;
-        const bool more = step + 1 < total_steps;
-        if (more) ISC_LOAD_STEP(step + 1);
+        // DMA for later steps first: B(step + 1) then A(step + 2) (issue order matters for the counted wait)
+        if (step + 1 < total_steps) {
+            if (DBG == 0 || DBG == 3 || DBG == 5) issue_b(step + 1);
+            else if (DBG == 1) issue_a(step + 1);  // keep the instruction count / vmcnt bookkeeping identical
+        }
+        if (step + 2 < total_steps && DBG != 2 && DBG != 5) issue_a(step + 2);
 
-        const unsigned char* a_img = lds + buf * TILE_BYTES + a_wave_off;
-        const unsigned char* b_img = lds + (2 + buf) * TILE_BYTES + b_wave_off;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            uint4 a[8], b[4];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) a[m] = *reinterpret_cast<const uint4*>(a_img + m * 2048 + foff[kk]);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const uint4*>(b_img + n * 2048 + foff[kk]);
-            Mma<T>::run(a, b, acc);
+        // fragment reads and MFMAs, software pipelined per 16-row block: the reads of block m + 1 are in flight
+        // while the matrix cores work on block m (LDS returns in order, so lgkmcnt(2) = "all but the newest two")
+        {
+            const unsigned a_addr = lds_a_addr + (unsigned)((step % A_STAGES) * TILE_BYTES + a_wave_off);
+            const unsigned b_addr = lds_b_addr + (unsigned)((step & 1) * TILE_BYTES + b_wave_off);
+            const unsigned a_addr0 = a_addr + foff[0], a_addr1 = a_addr + foff[1];
+            const unsigned b_addr0 = b_addr + foff[0], b_addr1 = b_addr + foff[1];
+            u32x4 bq[2][4], ar[2][2];
+            ISC_DS_READ(bq[0][0], b_addr0, 0);
+            ISC_DS_READ(bq[0][1], b_addr0, 2048);
+            ISC_DS_READ(bq[0][2], b_addr0, 4096);
+            ISC_DS_READ(bq[0][3], b_addr0, 6144);
+            ISC_DS_READ(bq[1][0], b_addr1, 0);
+            ISC_DS_READ(bq[1][1], b_addr1, 2048);
+            ISC_DS_READ(bq[1][2], b_addr1, 4096);
+            ISC_DS_READ(bq[1][3], b_addr1, 6144);
+            ISC_DS_READ(ar[0][0], a_addr0, 0);
+            ISC_DS_READ(ar[0][1], a_addr1, 0);
+#define ISC_ROW_STEP(m_, cur_, nxt_, wait_)                                                                          \
+    if ((m_) < 7) {                                                                                                  \
+        ISC_DS_READ(ar[nxt_][0], a_addr0, ((m_) + 1) * 2048);                                                        \
+        ISC_DS_READ(ar[nxt_][1], a_addr1, ((m_) + 1) * 2048);                                                        \
+    }                                                                                                                \
+    if ((m_) == 0)                                                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(2)"                                                                          \
+                     : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]), "+v"(bq[1][0]), "+v"(bq[1][1]),   \
+                       "+v"(bq[1][2]), "+v"(bq[1][3]), "+v"(ar[0][0]), "+v"(ar[0][1]));                                  \
+    else                                                                                                             \
+        asm volatile("s_waitcnt lgkmcnt(" wait_ ")" : "+v"(ar[cur_][0]), "+v"(ar[cur_][1]));                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    if (DBG < 3) Mma<T>::row(ar[cur_][0], ar[cur_][1], bq, acc[m_]);                                                \
+    else acc[m_][0][0] += __uint_as_float(ar[cur_][0][0] ^ ar[cur_][1][1] ^ bq[0][m_ & 3][0] ^ bq[1][m_ & 3][1]);
+            ISC_ROW_STEP(0, 0, 1, "2")
+            ISC_ROW_STEP(1, 1, 0, "2")
+            ISC_ROW_STEP(2, 0, 1, "2")
+            ISC_ROW_STEP(3, 1, 0, "2")
+            ISC_ROW_STEP(4, 0, 1, "2")
+            ISC_ROW_STEP(5, 1, 0, "2")
+            ISC_ROW_STEP(6, 0, 1, "2")
+            ISC_ROW_STEP(7, 1, 0, "0")
+#undef ISC_ROW_STEP
         }
 
         if (++kt == ksteps) {
@@ -312,7 +395,6 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const T* __restrict__ 
                 const int64_t trow0 = r0 + (int64_t)(tile_begin + tile) * TM + wm * 128 + fg * 4;
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    const int ql = n * 16 + frow;
 #pragma unroll
                     for (int m = 0; m < 8; ++m)
 #pragma unroll
@@ -320,8 +402,8 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const T* __restrict__ 
                             const float s = acc[m][n][r];
                             const int64_t row = trow0 + m * 16 + r;
                             if (s >= thr[n] && row < r1) {
-                                const int pos = atomicAdd(&cnt[ql], 1);
-                                if (pos < CAP) my_ent[(size_t)ql * CAP + pos] = Cand{s, (int32_t)row};
+                                const int pos = cnt[n]++;
+                                if (pos < CAP) my_ent[(size_t)n * 16 * CAP + pos] = Cand{s, (int32_t)row};
                             }
                         }
                 }
@@ -333,14 +415,22 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const T* __restrict__ 
             ++tile;
         }
 
-        if (more) ISC_STORE_STEP(buf ^ 1);
-        __syncthreads();
+        // retire this wave's DMA for step + 1 (bank step + 2, issued last, may stay in flight); the barrier then
+        // publishes every wave's pieces and guarantees nobody still reads the slots refilled next iteration
+        if (step + 2 < total_steps && DBG != 2 && DBG < 4) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
     }
 
-    // publish this wave's survivor counts
-    const int c = cnt[lane];
-    seg_cnt[(size_t)seg * qpad + q0 + wn * 64 + lane] = min(c, CAP);
-    if (c > CAP) atomicAdd(&status[0], 1);
+    // publish this lane's survivor counts
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        seg_cnt[(size_t)seg * qpad + q0 + wn * 64 + n * 16 + frow] = min(cnt[n], CAP);
+        if (cnt[n] > CAP) atomicAdd(&status[0], 1);
+    }
 }
 
 // (score desc, row asc); entries with row < 0 are empty
@@ -351,14 +441,16 @@ __device__ __forceinline__ bool better(float sa, int ra, float sb, int rb) {
 }
 
 // One workgroup per query: gather the survivors of every segment plus the carried list, keep the best kp.
+constexpr int MAX_SEG = SEGS_PER_CHUNK * MAX_CHUNKS;
 __global__ __launch_bounds__(256) void k_select(const int32_t* __restrict__ seg_cnt, const Cand* __restrict__ seg_ent,
                                                 int nseg, int qpad, int kp, float* __restrict__ tau,
                                                 float* __restrict__ carry_s, int32_t* __restrict__ carry_r,
                                                 int32_t* __restrict__ carry_n, int32_t* __restrict__ status) {
     __shared__ Cand cand[SELECT_CAP];
-    __shared__ int seg_off[2 * MAX_CHUNKS + 1];
+    __shared__ int seg_off[MAX_SEG + 1];
     __shared__ float red_s[4];
     __shared__ int red_r[4], red_p[4];
+    __shared__ int wave_tot[4];
     __shared__ int total_sh;
 
     const int q = blockIdx.x;
@@ -366,29 +458,36 @@ __global__ __launch_bounds__(256) void k_select(const int32_t* __restrict__ seg_
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    // exclusive scan of the segment counts (nseg <= 512: two per thread)
-    int c0 = 0, c1 = 0;
-    if (2 * tid < nseg) c0 = seg_cnt[(size_t)(2 * tid) * qpad + q];
-    if (2 * tid + 1 < nseg) c1 = seg_cnt[(size_t)(2 * tid + 1) * qpad + q];
-    int v = c0 + c1;
+    // exclusive scan of the segment counts: thread t owns segments [t * spt, (t + 1) * spt)
+    const int spt = (nseg + 255) / 256;
+    const int s_begin = tid * spt;
+    int v = 0;
+    for (int j = 0; j < spt; ++j) {
+        const int sidx = s_begin + j;
+        if (sidx < nseg) v += seg_cnt[(size_t)sidx * qpad + q];
+    }
     int incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const int t = __shfl_up(incl, off, 64);
         if (lane >= off) incl += t;
     }
-    __shared__ int wave_tot[4];
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
     int wbase = 0;
     for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
-    const int excl = wbase + incl - v;
-    if (2 * tid < nseg) seg_off[2 * tid] = excl;
-    if (2 * tid + 1 < nseg) seg_off[2 * tid + 1] = excl + c0;
+    int run = wbase + incl - v;
+    for (int j = 0; j < spt; ++j) {
+        const int sidx = s_begin + j;
+        if (sidx < nseg) {
+            seg_off[sidx] = run;
+            run += seg_cnt[(size_t)sidx * qpad + q];
+        }
+    }
     const int carried = carry_n[q];
     if (tid == 255) {
-        seg_off[nseg] = excl + v;
-        total_sh = excl + v + carried;
+        seg_off[nseg] = wbase + incl;
+        total_sh = wbase + incl + carried;
     }
     __syncthreads();
     int total = total_sh;
@@ -397,12 +496,14 @@ __global__ __launch_bounds__(256) void k_select(const int32_t* __restrict__ seg_
         if (tid == 0) atomicAdd(&status[0], 1);
         total = SELECT_CAP;
     }
-    // copy: each wave takes every 4th segment
-    for (int s = wave; s < nseg; s += 4) {
-        const int o = seg_off[s];
-        const int c = seg_off[s + 1] - o;
-        const Cand* src = seg_ent + ((size_t)s * qpad + q) * CAP;
-        for (int i = lane; i < c; i += 64)
+    // copy: thread t moves the (few) entries of its own segments
+    for (int j = 0; j < spt; ++j) {
+        const int sidx = s_begin + j;
+        if (sidx >= nseg) break;
+        const int o = seg_off[sidx];
+        const int c = seg_off[sidx + 1] - o;
+        const Cand* src = seg_ent + ((size_t)sidx * qpad + q) * CAP;
+        for (int i = 0; i < c; ++i)
             if (o + i < SELECT_CAP) cand[o + i] = src[i];
     }
     for (int i = tid; i < carried; i += 256)
@@ -459,8 +560,9 @@ __global__ __launch_bounds__(256) void k_select(const int32_t* __restrict__ seg_
 
 // One workgroup per query: exact float64 re-score of the carried candidates, final order, output.
 template <typename T>
-__global__ __launch_bounds__(256) void k_rescore(const T* __restrict__ bank, int64_t ldb, const T* __restrict__ queries,
-                                                 int64_t ldq, int d, int kp, int k, int64_t index_base,
+__global__ __launch_bounds__(256) void k_rescore(const unsigned char* __restrict__ bank, int ks,
+                                                 const T* __restrict__ queries, int64_t ldq, int d, int kp, int k,
+                                                 int64_t index_base,
                                                  const int32_t* __restrict__ carry_r,
                                                  const int32_t* __restrict__ carry_n, float* __restrict__ out_s,
                                                  int64_t* __restrict__ out_i) {
@@ -487,9 +589,8 @@ __global__ __launch_bounds__(256) void k_rescore(const T* __restrict__ bank, int
     const double denom = qnorm_sh;
     for (int c = wave; c < n; c += 4) {
         const int row = carry_r[(size_t)q * kp + c];
-        const T* bp = bank + (int64_t)row * ldb;
         double acc = 0.0;
-        for (int i = lane; i < d; i += 64) acc = fma((double)qp[i], (double)bp[i], acc);
+        for (int i = lane; i < d; i += 64) acc = fma((double)qp[i], (double)isc_packed_load<T>(bank, row, i, ks), acc);
         acc = isc_wave_sum(acc);
         if (lane == 0) {
             sc[c] = (float)(acc / denom);
@@ -509,27 +610,48 @@ __global__ __launch_bounds__(256) void k_rescore(const T* __restrict__ bank, int
     }
 }
 
+int debug_mode() {
+    static const int mode = [] {
+        const char* e = getenv("ISC_DEBUG_MODE");
+        return e ? atoi(e) : 0;
+    }();
+    return mode;
+}
+
 template <typename T>
-int run(const void* bank, int64_t n, int d, int64_t ldb, const void* queries, int q, int64_t ldq, int k,
-        int64_t index_base, float* out_s, int64_t* out_i, int32_t* status, void* ws_base, hipStream_t stream) {
+int run(const void* bank, int64_t n, int d, const void* queries, int q, int64_t ldq, int k, int64_t index_base,
+        float* out_s, int64_t* out_i, int32_t* status, void* ws_base, hipStream_t stream) {
     const Plan p = make_plan(n, q, k);
-    const Workspace w = carve(p, ws_base);
-    const int ksteps = d * (int)sizeof(T) / 128;
+    const int ksteps = isc_ksteps(d, (int)sizeof(T));
+    const Workspace w = carve(p, ksteps, ws_base);
+    const unsigned char* bank_bytes = static_cast<const unsigned char*>(bank);
     hipLaunchKernelGGL(k_init, dim3(isc_ceil_div(p.qpad, 256)), dim3(256), 0, stream, w.tau, w.carry_n, q, p.qpad,
                        status);
+    hipLaunchKernelGGL(k_pack_queries<T>, dim3(isc_ceil_div(p.qpad * ksteps * 8, 256)), dim3(256), 0, stream,
+                       static_cast<const T*>(queries), ldq, q, d, ksteps, p.qpad, w.qpacked);
     for (int level = 0;; ++level) {
         const Level l = make_level(level, n, p.qtiles);
         isc_timing_begin(ISC_KERNEL_DOTS_FILTER, stream);
-        hipLaunchKernelGGL(k_dots_filter<T>, dim3(l.nchunks, p.qtiles), dim3(NTHREADS), 0, stream,
-                           static_cast<const T*>(bank), ldb, n, l.r0, l.r1, l.tiles_per_chunk, l.ntiles,
-                           static_cast<const T*>(queries), ldq, q, ksteps, w.tau, p.qpad, w.seg_cnt, w.seg_ent, status);
+#define ISC_LAUNCH_FILTER(DBG_)                                                                                     \
+    hipLaunchKernelGGL((k_dots_filter<T, DBG_>), dim3(l.nchunks, p.qtiles), dim3(NTHREADS), 0, stream, bank_bytes,   \
+                       l.r0, l.r1, l.tiles_per_chunk, l.ntiles, w.qpacked, ksteps, w.tau, p.qpad, w.seg_cnt,         \
+                       w.seg_ent, status)
+        switch (debug_mode()) {
+            case 1: ISC_LAUNCH_FILTER(1); break;
+            case 2: ISC_LAUNCH_FILTER(2); break;
+            case 3: ISC_LAUNCH_FILTER(3); break;
+            case 4: ISC_LAUNCH_FILTER(4); break;
+            case 5: ISC_LAUNCH_FILTER(5); break;
+            default: ISC_LAUNCH_FILTER(0); break;
+        }
+#undef ISC_LAUNCH_FILTER
         isc_timing_end(ISC_KERNEL_DOTS_FILTER, stream);
-        hipLaunchKernelGGL(k_select, dim3(q), dim3(256), 0, stream, w.seg_cnt, w.seg_ent, 2 * l.nchunks, p.qpad, p.kp,
-                           w.tau, w.carry_s, w.carry_r, w.carry_n, status);
+        hipLaunchKernelGGL(k_select, dim3(q), dim3(256), 0, stream, w.seg_cnt, w.seg_ent, SEGS_PER_CHUNK * l.nchunks,
+                           p.qpad, p.kp, w.tau, w.carry_s, w.carry_r, w.carry_n, status);
         if (l.r1 >= n) break;
     }
-    hipLaunchKernelGGL(k_rescore<T>, dim3(q), dim3(256), 0, stream, static_cast<const T*>(bank), ldb,
-                       static_cast<const T*>(queries), ldq, d, p.kp, k, index_base, w.carry_r, w.carry_n, out_s, out_i);
+    hipLaunchKernelGGL(k_rescore<T>, dim3(q), dim3(256), 0, stream, bank_bytes, ksteps, static_cast<const T*>(queries),
+                       ldq, d, p.kp, k, index_base, w.carry_r, w.carry_n, out_s, out_i);
     return isc_launch_status();
 }
 
@@ -538,8 +660,7 @@ int check_args(int dtype, int64_t n, int d, int q, int k) {
     if (n <= 0 || d <= 0 || q <= 0 || k <= 0 || k > n) return ISC_ERR_INVALID_ARG;
     if (k > ISC_TOPK_MAX_K) return ISC_ERR_UNSUPPORTED;
     if (n > 0x7fffffff) return ISC_ERR_UNSUPPORTED;  // row ids are int32 inside a shard
-    const int esz = dtype == ISC_F16 ? 2 : 4;
-    if ((d * esz) % 128 != 0) return ISC_ERR_UNSUPPORTED;  // pad the embedding axis with zero columns
+    if (d > 65536) return ISC_ERR_UNSUPPORTED;
     if (isc_ceil_div(q, TN) > 65535) return ISC_ERR_UNSUPPORTED;
     return ISC_OK;
 }
@@ -550,26 +671,24 @@ extern "C" int isc_cosine_topk_workspace_bytes(int dtype, int64_t N, int D, int 
     ISC_REQUIRE(bytes);
     const int st = check_args(dtype, N, D, Q, k);
     if (st != ISC_OK) return st;
-    *bytes = carve(make_plan(N, Q, k), nullptr).bytes;
+    *bytes = carve(make_plan(N, Q, k), isc_ksteps(D, dtype == ISC_F16 ? 2 : 4), nullptr).bytes;
     return ISC_OK;
 }
 
-extern "C" int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, int64_t ldb, const void* queries, int Q,
-                               int64_t ldq, int k, int64_t index_base, float* out_scores, int64_t* out_indices,
-                               int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, const void* queries, int Q, int64_t ldq,
+                               int k, int64_t index_base, float* out_scores, int64_t* out_indices, int32_t* status,
+                               void* workspace, size_t workspace_bytes, void* stream) {
     ISC_REQUIRE(bank && queries && out_scores && out_indices && status);
     const int st = check_args(dtype, N, D, Q, k);
     if (st != ISC_OK) return st;
-    ISC_REQUIRE(ldb >= D && ldq >= D);
-    const int esz = dtype == ISC_F16 ? 2 : 4;
-    if (!isc_aligned(bank, 16) || !isc_aligned(queries, 16) || (ldb * esz) % 16 != 0 || (ldq * esz) % 16 != 0)
-        return ISC_ERR_ALIGNMENT;
+    ISC_REQUIRE(ldq >= D);
+    if (!isc_aligned(bank, 16) || !isc_aligned(workspace, 256)) return ISC_ERR_ALIGNMENT;
     size_t need = 0;
     isc_cosine_topk_workspace_bytes(dtype, N, D, Q, k, &need);
     if (!workspace || workspace_bytes < need) return ISC_ERR_WORKSPACE;
     if (dtype == ISC_F16)
-        return run<_Float16>(bank, N, D, ldb, queries, Q, ldq, k, index_base, out_scores, out_indices, status,
-                             workspace, isc_stream(stream));
-    return run<float>(bank, N, D, ldb, queries, Q, ldq, k, index_base, out_scores, out_indices, status, workspace,
+        return run<_Float16>(bank, N, D, queries, Q, ldq, k, index_base, out_scores, out_indices, status, workspace,
+                             isc_stream(stream));
+    return run<float>(bank, N, D, queries, Q, ldq, k, index_base, out_scores, out_indices, status, workspace,
                       isc_stream(stream));
 }

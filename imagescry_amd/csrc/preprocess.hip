@@ -277,24 +277,6 @@ __global__ __launch_bounds__(256) void k_l2norm_spatial(const float* __restrict_
     }
 }
 
-// One wave per bank row: optional L2 normalisation, cast to the bank dtype, zero-fill the padding columns.
-template <typename OUT>
-__global__ __launch_bounds__(256) void k_bank_from_rows(const float* __restrict__ x, int64_t N, int D, int64_t ldx,
-                                                        int normalize, float eps, OUT* __restrict__ y, int64_t ldy) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= N) return;
-    const int lane = threadIdx.x & 63;
-    const float* p = x + row * ldx;
-    float denom = 1.f;
-    if (normalize) {
-        float acc = 0.f;
-        for (int i = lane; i < D; i += 64) acc += p[i] * p[i];
-        denom = fmaxf(sqrtf(isc_wave_sum(acc)), eps);
-    }
-    OUT* o = y + row * ldy;
-    for (int i = lane; i < (int)ldy; i += 64) o[i] = i < D ? (OUT)(normalize ? __fdiv_rn(p[i], denom) : p[i]) : (OUT)0.f;
-}
-
 int grid_for(size_t work_items, int threads, int cap_blocks = 256 * 8) {
     size_t blocks = isc_ceil_div(work_items, (size_t)threads);
     if (blocks > (size_t)cap_blocks) blocks = cap_blocks;
@@ -405,21 +387,5 @@ extern "C" int isc_l2norm_channels(const float* x, int B, int E, int S, float ep
         hipLaunchKernelGGL(k_l2norm_spatial, dim3(isc_ceil_div(S, 64), B), dim3(256), 0, isc_stream(stream), x, E, S,
                            eps, y);
     }
-    return isc_launch_status();
-}
-
-extern "C" int isc_bank_from_rows(const float* x, int64_t N, int D, int64_t ldx, int normalize, float eps, void* y,
-                                  int out_dtype, int64_t ldy, void* stream) {
-    ISC_REQUIRE(x && y && N > 0 && D > 0 && ldx >= D && ldy >= D);
-    ISC_REQUIRE(out_dtype == ISC_F16 || out_dtype == ISC_F32);
-    if (ldy > 0x7fffffff) return ISC_ERR_UNSUPPORTED;
-    const int64_t blocks = isc_ceil_div<int64_t>(N, 4);
-    if (blocks > 0x7fffffff) return ISC_ERR_UNSUPPORTED;
-    if (out_dtype == ISC_F16)
-        hipLaunchKernelGGL(k_bank_from_rows<_Float16>, dim3((unsigned)blocks), dim3(256), 0, isc_stream(stream), x, N, D,
-                           ldx, normalize, eps, static_cast<_Float16*>(y), ldy);
-    else
-        hipLaunchKernelGGL(k_bank_from_rows<float>, dim3((unsigned)blocks), dim3(256), 0, isc_stream(stream), x, N, D,
-                           ldx, normalize, eps, static_cast<float*>(y), ldy);
     return isc_launch_status();
 }

@@ -1,5 +1,6 @@
 // Merge of partial top-k lists and the data-independent exhaustive search
 // (include/imagescry_hip.h: isc_topk_merge, isc_cosine_topk_exhaustive).
+#include "bank_layout.h"
 #include "isc_common.h"
 
 namespace {
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void k_topk_merge(const float* __restrict__ sc
 constexpr int EX_MAXK = ISC_TOPK_MAX_K;
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_exhaustive(const T* __restrict__ bank, int64_t ldb, int64_t n_rows,
+__global__ __launch_bounds__(256) void k_exhaustive(const unsigned char* __restrict__ bank, int ks, int64_t n_rows,
                                                     int64_t rows_per_chunk, const T* __restrict__ queries, int64_t ldq,
                                                     int d, int k, int64_t index_base, int Q,
                                                     float* __restrict__ part_s, int64_t* __restrict__ part_i) {
@@ -80,9 +81,8 @@ __global__ __launch_bounds__(256) void k_exhaustive(const T* __restrict__ bank, 
     const int64_t begin = (int64_t)chunk * rows_per_chunk;
     const int64_t end = min(n_rows, begin + rows_per_chunk);
     for (int64_t row = begin + wave; row < end; row += 4) {
-        const T* bp = bank + row * ldb;
         double acc = 0.0;
-        for (int i = lane; i < d; i += 64) acc = fma(qd[i], (double)bp[i], acc);
+        for (int i = lane; i < d; i += 64) acc = fma(qd[i], (double)isc_packed_load<T>(bank, row, i, ks), acc);
         acc = isc_wave_sum(acc);
         const float s = (float)(acc / denom);
         // rows arrive in ascending order, so an equal score never displaces an earlier row
@@ -165,14 +165,14 @@ extern "C" int isc_cosine_topk_exhaustive_workspace_bytes(int dtype, int64_t N, 
     return ISC_OK;
 }
 
-extern "C" int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N, int D, int64_t ldb,
-                                          const void* queries, int Q, int64_t ldq, int k, int64_t index_base,
+extern "C" int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N, int D, const void* queries, int Q,
+                                          int64_t ldq, int k, int64_t index_base,
                                           float* out_scores, int64_t* out_indices, void* workspace,
                                           size_t workspace_bytes, void* stream) {
     ISC_REQUIRE(bank && queries && out_scores && out_indices);
     const int st = ex_check(dtype, N, D, Q, k);
     if (st != ISC_OK) return st;
-    ISC_REQUIRE(ldb >= D && ldq >= D);
+    ISC_REQUIRE(ldq >= D);
     const ExPlan p = ex_plan(N, Q, k);
     if (!workspace || workspace_bytes < p.bytes) return ISC_ERR_WORKSPACE;
     float* part_s = static_cast<float*>(workspace);
@@ -181,11 +181,11 @@ extern "C" int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N
     hipStream_t s = isc_stream(stream);
     if (dtype == ISC_F16)
         hipLaunchKernelGGL(k_exhaustive<_Float16>, dim3(p.chunks, Q), dim3(256), lds, s,
-                           static_cast<const _Float16*>(bank), ldb, N, p.rows_per_chunk,
+                           static_cast<const unsigned char*>(bank), isc_ksteps(D, 2), N, p.rows_per_chunk,
                            static_cast<const _Float16*>(queries), ldq, D, k, index_base, Q, part_s, part_i);
     else
-        hipLaunchKernelGGL(k_exhaustive<float>, dim3(p.chunks, Q), dim3(256), lds, s, static_cast<const float*>(bank),
-                           ldb, N, p.rows_per_chunk, static_cast<const float*>(queries), ldq, D, k, index_base, Q,
+        hipLaunchKernelGGL(k_exhaustive<float>, dim3(p.chunks, Q), dim3(256), lds, s,
+                           static_cast<const unsigned char*>(bank), isc_ksteps(D, 4), N, p.rows_per_chunk, static_cast<const float*>(queries), ldq, D, k, index_base, Q,
                            part_s, part_i);
     hipLaunchKernelGGL(k_topk_merge, dim3(Q), dim3(256), 0, s, part_s, part_i, p.chunks * 4, Q, k, k, out_scores,
                        out_indices);

@@ -41,11 +41,6 @@ def shard_bounds(n_rows: int, world_size: int, rank: int) -> tuple[int, int]:
     return rank * n_rows // world_size, (rank + 1) * n_rows // world_size
 
 
-def _row_multiple(dtype: torch.dtype) -> int:
-    # one K step of the matrix-core kernel is 128 bytes of a row
-    return 64 if dtype == torch.float16 else 32
-
-
 class EmbeddingBank:
     """`[N, D]` embedding bank on one GPU (or one row shard of it per rank) with cosine top-k search.
 
@@ -56,8 +51,7 @@ class EmbeddingBank:
             its first row.
         dtype: storage dtype of the bank, `torch.float16` (default) or `torch.float32`.
         normalize: L2-normalise every row before storing it (skip for rows that are already unit length,
-            e.g. the output of `Embedder.predict_step`; a float16 input with `normalize=False` is used
-            without a copy).
+            e.g. the output of `Embedder.predict_step`).
         index_base: global row index of local row 0 (only with `presharded=True`).
         process_group: the `torch.distributed` group the bank is sharded over (`None` = single GPU).
     """
@@ -111,29 +105,33 @@ class EmbeddingBank:
         return cls(rows, **kwargs)  # type: ignore[arg-type]
 
     def _store(self, embeddings: Tensor, normalize: bool) -> Tensor:
-        """Row-normalise / cast / zero-pad the rows into the kernel's bank layout (`isc_bank_from_rows`)."""
+        """Row-normalise / cast the rows and write them into the PACKED bank image (`isc_bank_pack`):
+        `[tile of 256 rows][K step][row][128 B]`, the layout the search kernels stream (include/imagescry_hip.h)."""
         _lib.require_device(embeddings, "embeddings")
         n, d = embeddings.shape
-        mult = _row_multiple(self.dtype)
-        ld = (d + mult - 1) // mult * mult
-        if not normalize and embeddings.dtype == self.dtype and ld == d and embeddings.is_contiguous():
-            if embeddings.data_ptr() % 16 == 0:
-                return embeddings
-        bank = torch.empty((n, ld), dtype=self.dtype, device=embeddings.device)
-        if n == 0:
-            return bank
         lib = _lib.load()
+        code = _lib.dtype_code(self.dtype)
+        if n == 0:
+            return torch.empty(0, dtype=torch.uint8, device=embeddings.device)
+        need = _lib.c_size_t()
+        _lib.check(lib.isc_bank_packed_bytes(code, n, d, need), "isc_bank_packed_bytes")
+        packed = torch.empty(need.value, dtype=torch.uint8, device=embeddings.device)
+        tile_bytes = need.value // ((n + 255) // 256)
+        packed[-tile_bytes:].zero_()  # padding rows of the last tile (isc_bank_pack writes real rows only)
+        if embeddings.dtype not in (torch.float16, torch.float32):
+            embeddings = embeddings.float()
         block = 1 << 20
         with torch.cuda.device(embeddings.device):
             for r0 in range(0, n, block):
-                rows = embeddings[r0 : r0 + block].float().contiguous()
-                st = lib.isc_bank_from_rows(
-                    rows.data_ptr(), rows.shape[0], d, rows.stride(0), int(normalize), 1e-12,
-                    bank[r0 : r0 + block].data_ptr(), _lib.dtype_code(self.dtype), ld,
-                    _lib.stream_handle(embeddings.device),
+                rows = embeddings[r0 : r0 + block]
+                if rows.stride(1) != 1:
+                    rows = rows.contiguous()
+                st = lib.isc_bank_pack(
+                    rows.data_ptr(), _lib.dtype_code(rows.dtype), rows.shape[0], d, rows.stride(0), r0,
+                    int(normalize), 1e-12, packed.data_ptr(), code, _lib.stream_handle(embeddings.device),
                 )
-                _lib.check(st, "isc_bank_from_rows")
-        return bank
+                _lib.check(st, "isc_bank_pack")
+        return packed
 
     # ------------------------------------------------------------------ properties
     @property
@@ -142,8 +140,17 @@ class EmbeddingBank:
 
     @property
     def bank(self) -> Tensor:
-        """The stored `[N_local, D]` rows (a view without the zero padding columns)."""
-        return self._bank[:, : self.dim]
+        """The stored rows as a row-major `[N_local, D]` tensor of the bank dtype (unpacked copy, `isc_bank_unpack`)."""
+        out = torch.empty((self.num_local_rows, self.dim), dtype=self.dtype, device=self.device)
+        if self.num_local_rows:
+            lib = _lib.load()
+            with torch.cuda.device(self.device):
+                st = lib.isc_bank_unpack(
+                    self._bank.data_ptr(), _lib.dtype_code(self.dtype), self.dim, 0, self.num_local_rows,
+                    out.data_ptr(), self.dim, _lib.stream_handle(self.device),
+                )
+            _lib.check(st, "isc_bank_unpack")
+        return out
 
     def __len__(self) -> int:
         return self.num_local_rows
@@ -156,14 +163,7 @@ class EmbeddingBank:
             raise ValueError(f"queries must have shape [Q, {self.dim}], got {tuple(queries.shape)}")
         if queries.device != self.device:
             raise ValueError(f"queries are on {queries.device} but the bank is on {self.device}")
-        ld = self._bank.shape[1]
-        q = queries.to(self.dtype)
-        if ld != self.dim:
-            q = torch.nn.functional.pad(q, (0, ld - self.dim))
-        q = q.contiguous()
-        if q.data_ptr() % 16 != 0:  # pragma: no cover - torch allocations are 256-byte aligned
-            q = q.clone()
-        return q
+        return queries.to(self.dtype).contiguous()
 
     def _workspace(self, n_queries: int, k: int) -> Tensor:
         key = (n_queries, k)
@@ -172,7 +172,7 @@ class EmbeddingBank:
             lib = _lib.load()
             need = _lib.c_size_t()
             st = lib.isc_cosine_topk_workspace_bytes(
-                _lib.dtype_code(self.dtype), self.num_local_rows, self._bank.shape[1], n_queries, k, need
+                _lib.dtype_code(self.dtype), self.num_local_rows, self.dim, n_queries, k, need
             )
             _lib.check(st, "isc_cosine_topk_workspace_bytes")
             ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
@@ -189,8 +189,8 @@ class EmbeddingBank:
         lib = _lib.load()
         code = _lib.dtype_code(self.dtype)
         args = (
-            self._bank.data_ptr(), code, self.num_local_rows, self._bank.shape[1], self._bank.stride(0),
-            queries.data_ptr(), nq, queries.stride(0), k, self.index_base, scores.data_ptr(), indices.data_ptr(),
+            self._bank.data_ptr(), code, self.num_local_rows, self.dim, queries.data_ptr(), nq, queries.stride(0),
+            k, self.index_base, scores.data_ptr(), indices.data_ptr(),
         )
         with torch.cuda.device(self.device):
             stream = _lib.stream_handle(self.device)
@@ -202,9 +202,7 @@ class EmbeddingBank:
                 # redo this call with the data-independent float64 kernel
                 need = _lib.c_size_t()
                 _lib.check(
-                    lib.isc_cosine_topk_exhaustive_workspace_bytes(
-                        code, self.num_local_rows, self._bank.shape[1], nq, k, need
-                    ),
+                    lib.isc_cosine_topk_exhaustive_workspace_bytes(code, self.num_local_rows, self.dim, nq, k, need),
                     "isc_cosine_topk_exhaustive_workspace_bytes",
                 )
                 ews = torch.empty(need.value, dtype=torch.uint8, device=self.device)

@@ -96,12 +96,28 @@ int isc_resize_bilinear(const void* x, int dtype, int planes, int H1, int W1, in
  * Replaces `nn.functional.normalize(x, p=2, dim=1)` in reference src/imagescry/models/embedding.py:74. */
 int isc_l2norm_channels(const float* x, int B, int E, int S, float eps, float* y, void* stream);
 
-/* Row-wise L2 normalisation of a [N,D] float matrix (leading dimension ldx) into a bank of `out_dtype`
- * (ISC_F16 or ISC_F32, leading dimension ldy >= D; columns D..ldy-1 are zero-filled).  Same formula as above;
- * used once when an embedding bank is built from `EmbeddingBatch.get_flat_vectors()` rows
+/* Packed bank layout -- how an embedding bank sits in HBM for the search kernels.
+ * Rows are grouped in tiles of ISC_BANK_TILE_ROWS; inside a tile the embedding axis is cut into K steps of
+ * ISC_BANK_KSTEP_BYTES (64 halves / 32 floats, zero-padded) and stored step-major:
+ *     byte offset of (row r, K step s) = ((r / 256 * KS + s) * 256 + r % 256) * 128,   KS = ceil(D * esz / 128)
+ * so the 256 x 128 B block one K step of one tile needs is 32 KiB of CONTIGUOUS memory (one coalesced LDS-DMA
+ * stream per workgroup, every HBM channel in use) instead of 256 row segments 2*D bytes apart.  The row count is
+ * padded to a multiple of 256; the caller zero-fills the padding rows (isc_bank_pack only writes real rows). */
+#define ISC_BANK_TILE_ROWS 256
+#define ISC_BANK_KSTEP_BYTES 128
+int isc_bank_packed_bytes(int dtype, int64_t N, int D, size_t* bytes);
+
+/* Write rows [first_row, first_row + n_rows) of a bank into its packed image, optionally L2-normalising each row
+ * first with the formula above (x / max(||x||_2, eps), float32 arithmetic).  `rows` is row-major [n_rows, D] of
+ * `in_dtype` (ISC_F16 or ISC_F32, leading dimension ldx); `packed` holds `dtype` (ISC_F16 or ISC_F32).
+ * Used once when an embedding bank is built from `EmbeddingBatch.get_flat_vectors()` rows
  * (reference src/imagescry/data.py:112-118). */
-int isc_bank_from_rows(const float* x, int64_t N, int D, int64_t ldx, int normalize, float eps, void* y,
-                       int out_dtype, int64_t ldy, void* stream);
+int isc_bank_pack(const void* rows, int in_dtype, int64_t n_rows, int D, int64_t ldx, int64_t first_row, int normalize,
+                  float eps, void* packed, int dtype, void* stream);
+
+/* Inverse of isc_bank_pack for rows [first_row, first_row + n_rows): packed -> row-major [n_rows, D] of `dtype`. */
+int isc_bank_unpack(const void* packed, int dtype, int D, int64_t first_row, int64_t n_rows, void* rows, int64_t ldy,
+                    void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Encoder blocks (float32, NHWC activations, KRSC weights)
@@ -141,9 +157,9 @@ int isc_global_avgpool_nhwc(const float* x, int B, int H, int W, int C, float* y
  * No reference symbol exists; semantics are the oracle's
  * (oracle/search_oracle.py): score = float32(dot_f64(q,b) / max(||q||_2,1e-12)), bank rows used as
  * stored, result ordered by (score descending, row index ascending).
- *   bank         [N, D] of `dtype` (ISC_F16 or ISC_F32), leading dimension ldb (elements, % 8 == 0 for f16 / % 4 for f32,
- *                base pointer 16-byte aligned); D % 64 == 0 (f16) or % 32 == 0 (f32) -- pad with zero columns
- *   queries      [Q, D] of the SAME dtype, leading dimension ldq, same alignment rules
+ *   bank         N rows of D values of `dtype` (ISC_F16 or ISC_F32) in the PACKED layout above (isc_bank_pack),
+ *                16-byte aligned
+ *   queries      row-major [Q, D] of the SAME dtype, leading dimension ldq (elements)
  *   k            1 <= k <= min(N, ISC_TOPK_MAX_K)
  *   index_base   added to every returned row index (global index of this shard's row 0)
  *   out_scores   float   [Q, k]
@@ -154,15 +170,15 @@ int isc_global_avgpool_nhwc(const float* x, int B, int H, int W, int C, float* y
  */
 #define ISC_TOPK_MAX_K 120
 int isc_cosine_topk_workspace_bytes(int dtype, int64_t N, int D, int Q, int k, size_t* bytes);
-int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, int64_t ldb, const void* queries, int Q, int64_t ldq,
-                    int k, int64_t index_base, float* out_scores, int64_t* out_indices, int32_t* status,
+int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, const void* queries, int Q, int64_t ldq, int k,
+                    int64_t index_base, float* out_scores, int64_t* out_indices, int32_t* status,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same contract, data-independent cost: every score is evaluated in float64 and kept in a per-query list.
  * Slow (vector FMA, no matrix cores); the fallback for inputs whose candidate buffers overflow. */
 int isc_cosine_topk_exhaustive_workspace_bytes(int dtype, int64_t N, int D, int Q, int k, size_t* bytes);
-int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N, int D, int64_t ldb, const void* queries, int Q,
-                               int64_t ldq, int k, int64_t index_base, float* out_scores, int64_t* out_indices,
+int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N, int D, const void* queries, int Q, int64_t ldq,
+                               int k, int64_t index_base, float* out_scores, int64_t* out_indices,
                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* Merge G partial results (e.g. one per bank shard after the all-gather) into the final top-k by

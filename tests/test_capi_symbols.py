@@ -53,8 +53,10 @@ def test_host_only_entry_points(library: ctypes.CDLL) -> None:
     assert lib.isc_cosine_topk_workspace_bytes(_lib.ISC_F16, 256, 768, 1, 10, need) == 0
     small = need.value
     assert small < 2e6
-    # D must be a multiple of the 128-byte K step; k <= N; k <= ISC_TOPK_MAX_K
-    assert lib.isc_cosine_topk_workspace_bytes(_lib.ISC_F16, 1000, 100, 4, 10, need) == _lib.ISC_ERR_UNSUPPORTED
+    # k <= N; k <= ISC_TOPK_MAX_K; any D (the packed layout zero-pads the last K step)
+    assert lib.isc_cosine_topk_workspace_bytes(_lib.ISC_F16, 1000, 100, 4, 10, need) == 0
+    assert lib.isc_bank_packed_bytes(_lib.ISC_F16, 10_000_000, 768, need) == 0
+    assert need.value == 39063 * 12 * 256 * 128  # 39063 tiles x 12 K steps x 32 KiB
     assert lib.isc_cosine_topk_workspace_bytes(_lib.ISC_F32, 5, 32, 4, 10, need) == _lib.ISC_ERR_INVALID_ARG
     assert lib.isc_cosine_topk_workspace_bytes(_lib.ISC_F32, 500, 32, 4, 121, need) == _lib.ISC_ERR_UNSUPPORTED
     assert lib.isc_cosine_topk_workspace_bytes(_lib.ISC_U8, 500, 32, 4, 10, need) == _lib.ISC_ERR_INVALID_ARG

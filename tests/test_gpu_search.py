@@ -136,7 +136,8 @@ def test_exhaustive_kernel_matches_oracle(device: torch.device) -> None:
         bank, queries = cases.search_case(5000, 160, 11, dtype, seed=9)
         k = 10
         exp_s, exp_i = search_oracle.cosine_topk(bank, queries, k, index_base=1000)
-        b, q = bank.to(device), queries.to(device)
+        eb = _bank(bank, device)
+        q = queries.to(device)
         lib = _lib.load()
         need = _lib.c_size_t()
         code = _lib.dtype_code(dtype)
@@ -145,11 +146,20 @@ def test_exhaustive_kernel_matches_oracle(device: torch.device) -> None:
         s = torch.empty((11, k), dtype=torch.float32, device=device)
         i = torch.empty((11, k), dtype=torch.int64, device=device)
         st = lib.isc_cosine_topk_exhaustive(
-            b.data_ptr(), code, 5000, 160, 160, q.data_ptr(), 11, 160, k, 1000, s.data_ptr(), i.data_ptr(),
+            eb._bank.data_ptr(), code, 5000, 160, q.data_ptr(), 11, 160, k, 1000, s.data_ptr(), i.data_ptr(),
             ws.data_ptr(), ws.numel(), _lib.stream_handle(device),
         )
         _lib.check(st, "isc_cosine_topk_exhaustive")
         _check(s, i, exp_s, exp_i)
+
+
+def test_packed_bank_round_trip(device: torch.device) -> None:
+    """isc_bank_pack -> isc_bank_unpack returns the rows bit for bit (ragged N, D not a multiple of the K step)."""
+    for dtype in (torch.float16, torch.float32):
+        bank, _ = cases.search_case(1234, 100, 1, dtype, seed=4)
+        eb = _bank(bank, device)
+        assert torch.equal(eb.bank.cpu(), bank)
+        assert eb._bank.numel() == 5 * (2 if dtype == torch.float16 else 4) * 256 * 128
 
 
 def test_overflow_falls_back_to_exhaustive(device: torch.device) -> None:
