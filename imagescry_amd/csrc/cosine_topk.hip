@@ -2,11 +2,12 @@
 //
 // Pipeline per call (all on one stream, no host synchronisation):
 //
+//   k_pack_queries    queries -> the packed K-step-major layout of the bank (1.5 MiB at Q = 1024, L2 resident)
 //   for each level L (row ranges [0,4096), [4096,262144), [262144,16.7M), ... -- each 64x the previous):
-//     k_dots_filter   S = bank[rows] . queries^T on the matrix cores, 256x256 tiles.  The scores are never
-//                     written: each wave compares its accumulators with a per-query threshold tau (the kp-th
-//                     best score of the rows seen in the earlier levels) and appends the few survivors
-//                     (score, row) to a small per-(segment, query) buffer.  Level 0 runs with tau = -inf.
+//     k_dots_filter   S = bank[rows] . queries^T on the matrix cores.  The scores are never written: each lane
+//                     compares its accumulators with a per-query threshold tau (the kp-th best score of the rows
+//                     seen in the earlier levels) and appends the few survivors (score, row) to a small
+//                     per-(segment, query) buffer.  Level 0 runs with tau = -inf.
 //     k_select        per query: survivors + the carried list -> the best kp by (score desc, row asc);
 //                     tau <- the kp-th score.
 //   k_rescore         the kp = k + slack carried candidates are re-scored EXACTLY (float64 dot, float64 query
@@ -17,11 +18,18 @@
 //
 // Data layout.  The bank is PACKED (bank_layout.h): [tile of 256 rows][K step][row][128 B], so the block one K
 // step of one tile needs is 32 KiB of contiguous HBM and a workgroup's whole chunk is one linear stream.  The
-// queries are packed the same way per call (1.5 MiB, L2 resident).  Both MFMA operands are "K-major", so the same
-// staging code serves A (bank rows, the streamed operand) and B (queries).  One K step is 128 bytes of every row
-// (64 halves or 32 floats).  LDS tiles are [256 rows][128 B], the eight 16-byte chunks of a row XOR-swizzled with
-// (row >> 1) & 7 so that a ds_read_b128 of an MFMA fragment (16 rows x 4 chunks per wave) is bank-conflict free;
-// the LDS image is lane-linear in the staging order (the swizzle is applied to the LDS-DMA source address).
+// queries are packed the same way per call.  Both MFMA operands are "K-major", so the same staging code serves A
+// (bank rows, the streamed operand) and B (queries).  One K step is 128 bytes of every row (64 halves or 32
+// floats).  LDS tiles are [rows][128 B], the eight 16-byte chunks of a row XOR-swizzled with (row >> 1) & 7 so
+// that a ds_read_b128 of an MFMA fragment (16 rows x 4 chunks per wave) is bank-conflict free; the LDS image is
+// lane-linear in the staging order (the swizzle is applied to the LDS-DMA source address).
+//
+// Two tile shapes share the kernel template:
+//   TNQ = 256  256 bank rows x 256 queries per workgroup, waves 2 x 4 (128 x 64 each): the MFMA-bound shape for
+//              large query batches (arithmetic intensity 128 flop per staged byte);
+//   TNQ = 64   256 bank rows x  64 queries, waves 8 x 1 (32 x 64 each), a 4-deep ring for both operands: the
+//              HBM-bound shape for small query batches -- three 32 KiB bank blocks are in flight per CU while the
+//              matrix cores idle most of the time.
 #include <stdlib.h>
 
 #include "bank_layout.h"
@@ -31,18 +39,19 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TM = 256;        // bank rows per tile
-constexpr int TN = 256;        // queries per tile
-constexpr int NTHREADS = 512;  // 8 waves: 2 along the bank rows x 4 along the queries, 128 x 64 outputs each
-constexpr int CAP = 32;        // candidate slots per (segment, query); a segment = (chunk, row-half wave, lane group)
+constexpr int NTHREADS = 512;  // 8 waves
+constexpr int CAP = 32;        // candidate slots per (segment, query); segment = (chunk, row-block wave, lane group)
 constexpr int64_t LEVEL0_ROWS = 4096;
 constexpr int LEVEL_RATIO = 64;
-constexpr int TARGET_WGS = 256;  // one workgroup per MI355X CU (the kernel needs 130 KiB of LDS)
+constexpr int TARGET_WGS = 256;  // one workgroup per MI355X CU (the kernel uses all 160 KiB of LDS)
 constexpr int MAX_CHUNKS = 256;
-constexpr int SELECT_CAP = 8192;  // candidates one k_select workgroup can hold in LDS
+constexpr int SELECT_CAP = 4096;  // candidates one k_select workgroup can hold in LDS (level 0 produces 4096)
 constexpr int SLACK = 6;
-constexpr int SEGS_PER_CHUNK = 8;  // 2 row-half waves x 4 lane groups, each with private survivor counters
+constexpr int SMALL_Q = 128;  // up to this many queries the 64-query tile shape is used
+constexpr int MAX_SEG = 32 * MAX_CHUNKS;
 
 struct Cand {
     float s;
@@ -50,10 +59,12 @@ struct Cand {
 };
 
 struct Plan {
-    int kp;       // candidates carried per query (>= k + SLACK, multiple of 16)
-    int qtiles;   // ceil(Q / 256)
-    int qpad;     // qtiles * 256
-    int max_seg;  // SEGS_PER_CHUNK * max chunks over the levels
+    int tnq;             // queries per tile: 64 or 256
+    int segs_per_chunk;  // (8 / (tnq / 64)) row-block waves x 4 lane groups
+    int kp;              // candidates carried per query (>= k + SLACK, multiple of 16)
+    int qtiles;          // ceil(Q / tnq)
+    int qpad;            // qtiles * tnq
+    int max_seg;         // segs_per_chunk * max chunks over the levels
 };
 
 struct Level {
@@ -86,28 +97,39 @@ Level make_level(int level, int64_t n, int qtiles) {
     return l;
 }
 
+int forced_tile() {
+    static const int v = [] {
+        const char* e = getenv("ISC_FORCE_TILE");  // bring-up / benchmarking aid: 64 or 256
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 Plan make_plan(int64_t n, int q, int k) {
     Plan p;
+    p.tnq = q <= SMALL_Q ? 64 : 256;
+    if (forced_tile() == 64 || forced_tile() == 256) p.tnq = forced_tile();
+    p.segs_per_chunk = (8 / (p.tnq / 64)) * 4;
     p.kp = plan_kp(k);
-    p.qtiles = isc_ceil_div(q, TN);
-    p.qpad = p.qtiles * TN;
+    p.qtiles = isc_ceil_div(q, p.tnq);
+    p.qpad = p.qtiles * p.tnq;
     p.max_seg = 0;
     for (int level = 0;; ++level) {
         const Level l = make_level(level, n, p.qtiles);
-        if (SEGS_PER_CHUNK * l.nchunks > p.max_seg) p.max_seg = SEGS_PER_CHUNK * l.nchunks;
+        if (p.segs_per_chunk * l.nchunks > p.max_seg) p.max_seg = p.segs_per_chunk * l.nchunks;
         if (l.r1 >= n) break;
     }
     return p;
 }
 
 struct Workspace {
-    float* tau;        // [qpad]
-    float* carry_s;    // [qpad][kp]
-    int32_t* carry_r;  // [qpad][kp]
-    int32_t* carry_n;  // [qpad]
-    int32_t* seg_cnt;  // [max_seg][qpad]
-    Cand* seg_ent;     // [max_seg][qpad][CAP]
-    unsigned char* qpacked;  // [qtiles][ks][256][128 B]
+    float* tau;              // [qpad]
+    float* carry_s;          // [qpad][kp]
+    int32_t* carry_r;        // [qpad][kp]
+    int32_t* carry_n;        // [qpad]
+    int32_t* seg_cnt;        // [max_seg][qpad]
+    Cand* seg_ent;           // [max_seg][qpad][CAP]
+    unsigned char* qpacked;  // [qtiles][ks][tnq][128 B]
     size_t bytes;
 };
 
@@ -125,7 +147,7 @@ Workspace carve(const Plan& p, int ks, void* base) {
     w.carry_n = static_cast<int32_t*>(take((size_t)p.qpad * 4));
     w.seg_cnt = static_cast<int32_t*>(take((size_t)p.max_seg * p.qpad * 4));
     w.seg_ent = static_cast<Cand*>(take((size_t)p.max_seg * p.qpad * CAP * sizeof(Cand)));
-    w.qpacked = static_cast<unsigned char*>(take((size_t)p.qtiles * ks * ISC_TILE_KSTEP_BYTES));
+    w.qpacked = static_cast<unsigned char*>(take((size_t)p.qpad * ks * ISC_KSTEP_BYTES));
     w.bytes = off;
     return w;
 }
@@ -139,20 +161,20 @@ __global__ void k_init(float* tau, int32_t* carry_n, int q, int qpad, int32_t* s
     if (i < 4) status[i] = 0;
 }
 
-// queries row-major [q][ldq] -> packed [qtile][K step][256][128 B]; rows >= q and columns >= d are zero.
+// queries row-major [q][ldq] -> packed [qtile][K step][tnq rows][128 B]; rows >= q and columns >= d are zero.
 // One thread per 16-byte chunk.
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_queries(const T* __restrict__ queries, int64_t ldq, int q, int d, int ks,
-                                                      int qpad, unsigned char* __restrict__ packed) {
+                                                      int qpad, int tnq, unsigned char* __restrict__ packed) {
     constexpr int PER = 16 / (int)sizeof(T);
     const int total = qpad * ks * 8;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int c = i & 7;
-    const int row = (i >> 3) % ISC_TILE_ROWS;
-    const int blk = (i >> 3) / ISC_TILE_ROWS;  // qtile * ks + kstep
+    const int row = (i >> 3) % tnq;
+    const int blk = (i >> 3) / tnq;  // qtile * ks + kstep
     const int kstep = blk % ks;
-    const int qrow = (blk / ks) * ISC_TILE_ROWS + row;
+    const int qrow = (blk / ks) * tnq + row;
     T v[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -163,8 +185,6 @@ __global__ __launch_bounds__(256) void k_pack_queries(const T* __restrict__ quer
 }
 
 // --- operand traits -------------------------------------------------------------------------------------------
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 template <typename T>
 struct Mma;
 
@@ -212,134 +232,159 @@ struct Mma<float> {
 #define ISC_DS_READ(dst_, addr_, off_) \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_))
 
-// LDS map: a 3-deep ring of bank tiles (A) and a 2-deep ring of query tiles (B), 32 KiB each: exactly 160 KiB.
-constexpr int TILE_BYTES = TM * 128;
-constexpr int A_STAGES = 3;
-constexpr int B_STAGES = 2;
-constexpr int LDS_BYTES = (A_STAGES + B_STAGES) * TILE_BYTES;
-
 // Direct global -> LDS copy (LDS-DMA): lane l of the wave writes 16 bytes at lds_wave_base + 16 * l.
 __device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// One workgroup = one 256-query tile x one chunk of consecutive 256-row bank tiles.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt range");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+constexpr int A_TILE_BYTES = TM * 128;  // 32 KiB: one K step of one bank tile
+
+// One workgroup = one query tile x one chunk of consecutive 256-row bank tiles.
 //
-// Pipeline: K steps of all the chunk's tiles form one stream.  Iteration k issues the LDS-DMA of query step
-// k + 1 and bank step k + 2, computes step k, then waits with a COUNTED vmcnt (the bank step issued last stays
-// in flight) and a raw s_barrier -- two K steps (~4096 MFMA cycles) of HBM latency are covered without holding a
-// single staging register.  Ordering rules (cdna_hip_programming.md, "Pipelining across barriers"): a slot is
+// Pipeline: the K steps of all the chunk's tiles form one stream.  Iteration s issues the LDS-DMA of query step
+// s + DB and bank step s + DA, computes step s, then waits with a COUNTED vmcnt (only what step s + 1 needs is
+// retired; later steps stay in flight) and a raw s_barrier -- DA K steps of HBM latency are covered without holding
+// a single staging register.  Ordering rules (cdna_hip_programming.md, "Pipelining across barriers"): a slot is
 // read one iteration after the vmcnt + barrier that retires its DMA, and refilled one barrier after its last read.
-// DBG is a bring-up aid (ISC_DEBUG_MODE environment variable, never set in production): 1 = query tile staged only
-// once per chunk, 2 = no staging at all after the prologue, 3 = staging but no MFMAs, 4 / 5 = like 3 with only the bank / only the query stream (drained every step).  Results are wrong for != 0.
-template <typename T, int DBG>
+//
+// DBG is a bring-up aid (ISC_DEBUG_MODE environment variable, never set in production): 2 = no staging after the
+// prologue, 3 = staging but no MFMAs.  Results are wrong for DBG != 0.
+template <typename T, int TNQ, int DBG>
 __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* __restrict__ bank, int64_t r0,
                                                           int64_t r1, int tiles_per_chunk, int ntiles,
                                                           const unsigned char* __restrict__ qpacked, int ksteps,
                                                           const float* __restrict__ tau, int qpad,
                                                           int32_t* __restrict__ seg_cnt, Cand* __restrict__ seg_ent,
                                                           int32_t* __restrict__ status) {
+    constexpr int WN = TNQ / 64;              // waves along the queries
+    constexpr int WM = 8 / WN;                // waves along the bank rows
+    constexpr int MB = TM / WM / 16;          // 16-row blocks per wave: 8 (TNQ 256) or 2 (TNQ 64)
+    constexpr int B_TILE_BYTES = TNQ * 128;   // one K step of the query tile
+    constexpr int NA = 4;                     // LDS-DMA instructions per thread per bank step (512 x 16 B x 4)
+    constexpr int NB = B_TILE_BYTES / 8192;   // ... per query step: 4 or 1
+    constexpr int A_ST = TNQ == 256 ? 3 : 4;  // ring depths: together exactly 160 KiB
+    constexpr int B_ST = TNQ == 256 ? 2 : 4;
+    constexpr int DA = A_ST - 1;  // prefetch distances, in K steps
+    constexpr int DB = B_ST - 1;
+    constexpr int LDS_BYTES = A_ST * A_TILE_BYTES + B_ST * B_TILE_BYTES;
+    static_assert(LDS_BYTES == 163840, "the two rings fill the CU's LDS exactly");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];  // the ONLY LDS object (see the guide)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 2;  // 0..1 : which 128 bank rows of the tile
-    const int wn = wave & 3;   // 0..3 : which 64 queries of the tile
+    const int wm = wave / WN;  // which TM / WM bank rows of the tile
+    const int wn = wave % WN;  // which 64 queries of the tile
     const int chunk = blockIdx.x;
     const int qt = blockIdx.y;
-    const int q0 = qt * TN;
+    const int q0 = qt * TNQ;
 
     const int tile_begin = chunk * tiles_per_chunk;
     const int tile_end = min(ntiles, tile_begin + tiles_per_chunk);
     const int my_tiles = tile_end - tile_begin;
+    const int total_steps = my_tiles * ksteps;
+
+    const int frow = lane & 15;
+    const int fg = lane >> 4;
 
     // thresholds of this lane's four query columns, and this lane's private survivor counters
     float thr[4];
     int cnt[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-        thr[n] = tau[q0 + wn * 64 + n * 16 + (lane & 15)];
+        thr[n] = tau[q0 + wn * 64 + n * 16 + frow];
         cnt[n] = 0;
     }
 
-    // --- staging: the K-step block of a tile is 32 KiB contiguous in memory ([row][128 B]); staging round i moves
-    // slots p = tid + 512 * i (row p >> 3, 16-byte chunk p & 7) so that every wave instruction reads and writes one
-    // contiguous KiB.  The LDS image is lane-linear; the XOR swizzle is applied to the SOURCE chunk index.
+    // --- staging: a K-step block is contiguous in memory ([row][128 B]); staging round i moves slots
+    // p = tid + 512 * i (row p >> 3, 16-byte chunk p & 7), so every wave instruction reads and writes one contiguous
+    // KiB.  The LDS image is lane-linear; the XOR swizzle is applied to the SOURCE chunk index.
     const int srow = tid >> 3;
     const int spc = tid & 7;
     const int slot_src = srow * 128 + ((spc ^ ((srow >> 1) & 7)) << 4);  // (srow + 64 i) >> 1: same low bits for all i
-    // chunk of this workgroup: tiles are consecutive, so (tile, K step) -> one linear stream of 32 KiB blocks
-    const unsigned char* a_stream = bank + ((r0 >> 8) + tile_begin) * (int64_t)ksteps * ISC_TILE_KSTEP_BYTES + slot_src;
-    const unsigned char* b_stream = qpacked + (int64_t)qt * ksteps * ISC_TILE_KSTEP_BYTES + slot_src;
+    const unsigned char* a_stream = bank + ((r0 >> 8) + tile_begin) * (int64_t)ksteps * A_TILE_BYTES + slot_src;
+    const unsigned char* b_stream = qpacked + (int64_t)qt * ksteps * B_TILE_BYTES + slot_src;
 
     unsigned char* const lds_a = lds;
-    unsigned char* const lds_b = lds + A_STAGES * TILE_BYTES;
+    unsigned char* const lds_b = lds + A_ST * A_TILE_BYTES;
     const unsigned lds_a_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const unsigned lds_b_addr = lds_a_addr + A_STAGES * TILE_BYTES;
+    const unsigned lds_b_addr = lds_a_addr + A_ST * A_TILE_BYTES;
     const int wave_dst = wave * 1024;  // + 8192 * i: this wave's 1 KiB piece of staging round i
 
     auto issue_a = [&](int step) {
-        const unsigned char* src = a_stream + (int64_t)step * ISC_TILE_KSTEP_BYTES;
-        unsigned char* dst = lds_a + (step % A_STAGES) * TILE_BYTES + wave_dst;
+        const unsigned char* src = a_stream + (int64_t)step * A_TILE_BYTES;
+        unsigned char* dst = lds_a + (step % A_ST) * A_TILE_BYTES + wave_dst;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(src + 8192 * i, dst + 8192 * i);
+        for (int i = 0; i < NA; ++i) glds16(src + 8192 * i, dst + 8192 * i);
     };
     auto issue_b = [&](int step) {
-        const unsigned char* src = b_stream + (int64_t)(step % ksteps) * ISC_TILE_KSTEP_BYTES;
-        unsigned char* dst = lds_b + (step & 1) * TILE_BYTES + wave_dst;
+        const unsigned char* src = b_stream + (int64_t)(step % ksteps) * B_TILE_BYTES;
+        unsigned char* dst = lds_b + (step % B_ST) * B_TILE_BYTES + wave_dst;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(src + 8192 * i, dst + 8192 * i);
+        for (int i = 0; i < NB; ++i) glds16(src + 8192 * i, dst + 8192 * i);
+    };
+    // what iteration `it` issues (it < 0: prologue): first the query step, then the bank step
+    auto issue_iter = [&](int it) {
+        if (DBG == 2 && it >= 0) return;
+        const int sb = it + DB, sa = it + DA;
+        if (sb >= 0 && sb < total_steps) issue_b(sb);
+        if (sa >= 0 && sa < total_steps) issue_a(sa);
+    };
+    // after iteration `next - 1` has issued: retire everything step `next` needs, leave the younger DMA in flight
+    auto retire_for = [&](int next) {
+        if (DBG == 2) {
+            wait_vmcnt<0>();
+            return;
+        }
+        if (TNQ == 256) {  // stream order ... B(next) A(next + 1): only A(next + 1) may stay in flight
+            if (next + 1 < total_steps) wait_vmcnt<NA>();
+            else wait_vmcnt<0>();
+        } else {  // stream order ... B(next) A(next) | B(next+1) A(next+1) | B(next+2) A(next+2)
+            const int ahead = min(2, total_steps - 1 - next);
+            if (ahead >= 2) wait_vmcnt<2 * (NA + NB)>();
+            else if (ahead == 1) wait_vmcnt<NA + NB>();
+            else wait_vmcnt<0>();
+        }
     };
 
     // --- fragment read offsets (bytes inside a tile image)
-    const int frow = lane & 15;
-    const int fg = lane >> 4;
     const int fsw = (lane >> 1) & 7;
     int foff[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) foff[kk] = frow * 128 + (((kk * 4 + fg) ^ fsw) << 4);
-    const int a_wave_off = wm * 128 * 128;
+    const int a_wave_off = wm * (TM / WM) * 128;
     const int b_wave_off = wn * 64 * 128;
 
-    f32x4 acc[8][4];
+    f32x4 acc[MB][4];
 #pragma unroll
-    for (int m = 0; m < 8; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int total_steps = my_tiles * ksteps;
-    const int seg = (chunk * 2 + wm) * 4 + fg;
+    const int seg = (chunk * WM + wm) * 4 + fg;
     Cand* my_ent = seg_ent + ((size_t)seg * qpad + q0 + wn * 64 + frow) * CAP;  // + n * 16 * CAP
 
-    // prologue: B(0), A(0), A(1) in this order, so that a vmcnt(4) leaves exactly A(1) in flight
-    if (total_steps > 0) {
-        issue_b(0);
-        issue_a(0);
-        if (total_steps > 1) {
-            issue_a(1);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
+    // prologue: what iterations -DA .. -1 would have issued; then publish step 0
+    for (int it = -DA; it < 0; ++it) issue_iter(it);
+    retire_for(0);
     __builtin_amdgcn_s_barrier();
 
     int kt = 0, tile = 0;
     for (int step = 0; step < total_steps; ++step) {
-        // DMA for later steps first: B(step + 1) then A(step + 2) (issue order matters for the counted wait)
-        if (step + 1 < total_steps) {
-            if (DBG == 0 || DBG == 3 || DBG == 5) issue_b(step + 1);
-            else if (DBG == 1) issue_a(step + 1);  // keep the instruction count / vmcnt bookkeeping identical
-        }
-        if (step + 2 < total_steps && DBG != 2 && DBG != 5) issue_a(step + 2);
+        issue_iter(step);
 
         // fragment reads and MFMAs, software pipelined per 16-row block: the reads of block m + 1 are in flight
         // while the matrix cores work on block m (LDS returns in order, so lgkmcnt(2) = "all but the newest two")
         {
-            const unsigned a_addr = lds_a_addr + (unsigned)((step % A_STAGES) * TILE_BYTES + a_wave_off);
-            const unsigned b_addr = lds_b_addr + (unsigned)((step & 1) * TILE_BYTES + b_wave_off);
+            const unsigned a_addr = lds_a_addr + (unsigned)((step % A_ST) * A_TILE_BYTES + a_wave_off);
+            const unsigned b_addr = lds_b_addr + (unsigned)((step % B_ST) * B_TILE_BYTES + b_wave_off);
             const unsigned a_addr0 = a_addr + foff[0], a_addr1 = a_addr + foff[1];
             const unsigned b_addr0 = b_addr + foff[0], b_addr1 = b_addr + foff[1];
             u32x4 bq[2][4], ar[2][2];
@@ -353,50 +398,52 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             ISC_DS_READ(bq[1][3], b_addr1, 6144);
             ISC_DS_READ(ar[0][0], a_addr0, 0);
             ISC_DS_READ(ar[0][1], a_addr1, 0);
-#define ISC_ROW_STEP(m_, cur_, nxt_, wait_)                                                                          \
-    if ((m_) < 7) {                                                                                                  \
-        ISC_DS_READ(ar[nxt_][0], a_addr0, ((m_) + 1) * 2048);                                                        \
-        ISC_DS_READ(ar[nxt_][1], a_addr1, ((m_) + 1) * 2048);                                                        \
-    }                                                                                                                \
-    if ((m_) == 0)                                                                                                   \
-        asm volatile("s_waitcnt lgkmcnt(2)"                                                                          \
-                     : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]), "+v"(bq[1][0]), "+v"(bq[1][1]),   \
-                       "+v"(bq[1][2]), "+v"(bq[1][3]), "+v"(ar[0][0]), "+v"(ar[0][1]));                                  \
-    else                                                                                                             \
-        asm volatile("s_waitcnt lgkmcnt(" wait_ ")" : "+v"(ar[cur_][0]), "+v"(ar[cur_][1]));                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                               \
-    if (DBG < 3) Mma<T>::row(ar[cur_][0], ar[cur_][1], bq, acc[m_]);                                                \
-    else acc[m_][0][0] += __uint_as_float(ar[cur_][0][0] ^ ar[cur_][1][1] ^ bq[0][m_ & 3][0] ^ bq[1][m_ & 3][1]);
-            ISC_ROW_STEP(0, 0, 1, "2")
-            ISC_ROW_STEP(1, 1, 0, "2")
-            ISC_ROW_STEP(2, 0, 1, "2")
-            ISC_ROW_STEP(3, 1, 0, "2")
-            ISC_ROW_STEP(4, 0, 1, "2")
-            ISC_ROW_STEP(5, 1, 0, "2")
-            ISC_ROW_STEP(6, 0, 1, "2")
-            ISC_ROW_STEP(7, 1, 0, "0")
+#define ISC_ROW_STEP(m_, cur_, nxt_)                                                                                 \
+    if constexpr ((m_) < MB) {                                                                                       \
+        if constexpr ((m_) + 1 < MB) {                                                                               \
+            ISC_DS_READ(ar[nxt_][0], a_addr0, ((m_) + 1) * 2048);                                                    \
+            ISC_DS_READ(ar[nxt_][1], a_addr1, ((m_) + 1) * 2048);                                                    \
+        }                                                                                                            \
+        if constexpr ((m_) == 0)                                                                                     \
+            asm volatile("s_waitcnt lgkmcnt(2)"                                                                      \
+                         : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]), "+v"(bq[1][0]),           \
+                           "+v"(bq[1][1]), "+v"(bq[1][2]), "+v"(bq[1][3]), "+v"(ar[0][0]), "+v"(ar[0][1]));          \
+        else if constexpr ((m_) + 1 < MB)                                                                            \
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ar[cur_][0]), "+v"(ar[cur_][1]));                            \
+        else                                                                                                         \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[cur_][0]), "+v"(ar[cur_][1]));                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if constexpr (DBG < 3)                                                                                       \
+            Mma<T>::row(ar[cur_][0], ar[cur_][1], bq, acc[m_]);                                                      \
+        else                                                                                                         \
+            acc[m_][0][0] += __uint_as_float(ar[cur_][0][0] ^ ar[cur_][1][1] ^ bq[0][1][0] ^ bq[1][2][1]);           \
+    }
+            ISC_ROW_STEP(0, 0, 1)
+            ISC_ROW_STEP(1, 1, 0)
+            ISC_ROW_STEP(2, 0, 1)
+            ISC_ROW_STEP(3, 1, 0)
+            ISC_ROW_STEP(4, 0, 1)
+            ISC_ROW_STEP(5, 1, 0)
+            ISC_ROW_STEP(6, 0, 1)
+            ISC_ROW_STEP(7, 1, 0)
 #undef ISC_ROW_STEP
         }
 
         if (++kt == ksteps) {
             // ---- tile finished: threshold filter.  C layout of the 16x16 MFMA: column (query) = lane & 15,
-            // row (bank row) = 4 * (lane >> 4) + register.
+            // row (bank row) = 4 * (lane >> 4) + register.  Survivors are rare once tau is warm, so the scan of a
+            // query block only runs when some lane of the wave holds one (wave-uniform branch).
             kt = 0;
-            bool any = false;
+            const int64_t trow0 = r0 + (int64_t)(tile_begin + tile) * TM + wm * (TM / WM) + fg * 4;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 float mx = -INFINITY;
 #pragma unroll
-                for (int m = 0; m < 8; ++m)
+                for (int m = 0; m < MB; ++m)
                     mx = fmaxf(mx, fmaxf(fmaxf(acc[m][n][0], acc[m][n][1]), fmaxf(acc[m][n][2], acc[m][n][3])));
-                any |= (mx >= thr[n]);
-            }
-            if (__ballot(any) != 0ull) {
-                const int64_t trow0 = r0 + (int64_t)(tile_begin + tile) * TM + wm * 128 + fg * 4;
+                if (__ballot(mx >= thr[n]) != 0ull) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-#pragma unroll
-                    for (int m = 0; m < 8; ++m)
+                    for (int m = 0; m < MB; ++m)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float s = acc[m][n][r];
@@ -409,19 +456,15 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                 }
             }
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
             ++tile;
         }
 
-        // retire this wave's DMA for step + 1 (bank step + 2, issued last, may stay in flight); the barrier then
-        // publishes every wave's pieces and guarantees nobody still reads the slots refilled next iteration
-        if (step + 2 < total_steps && DBG != 2 && DBG < 4) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // retire this wave's DMA for step + 1; the barrier then publishes every wave's pieces and guarantees nobody
+        // still reads the slots refilled next iteration
+        retire_for(step + 1);
         __builtin_amdgcn_s_barrier();
     }
 
@@ -441,7 +484,6 @@ __device__ __forceinline__ bool better(float sa, int ra, float sb, int rb) {
 }
 
 // One workgroup per query: gather the survivors of every segment plus the carried list, keep the best kp.
-constexpr int MAX_SEG = SEGS_PER_CHUNK * MAX_CHUNKS;
 __global__ __launch_bounds__(256) void k_select(const int32_t* __restrict__ seg_cnt, const Cand* __restrict__ seg_ent,
                                                 int nseg, int qpad, int kp, float* __restrict__ tau,
                                                 float* __restrict__ carry_s, int32_t* __restrict__ carry_r,
@@ -562,8 +604,7 @@ __global__ __launch_bounds__(256) void k_select(const int32_t* __restrict__ seg_
 template <typename T>
 __global__ __launch_bounds__(256) void k_rescore(const unsigned char* __restrict__ bank, int ks,
                                                  const T* __restrict__ queries, int64_t ldq, int d, int kp, int k,
-                                                 int64_t index_base,
-                                                 const int32_t* __restrict__ carry_r,
+                                                 int64_t index_base, const int32_t* __restrict__ carry_r,
                                                  const int32_t* __restrict__ carry_n, float* __restrict__ out_s,
                                                  int64_t* __restrict__ out_i) {
     __shared__ float sc[128];
@@ -618,6 +659,21 @@ int debug_mode() {
     return mode;
 }
 
+template <typename T, int TNQ>
+void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsigned char* bank, int ksteps,
+                   int32_t* status, hipStream_t stream) {
+#define ISC_LAUNCH_FILTER(DBG_)                                                                                      \
+    hipLaunchKernelGGL((k_dots_filter<T, TNQ, DBG_>), dim3(l.nchunks, p.qtiles), dim3(NTHREADS), 0, stream, bank,    \
+                       l.r0, l.r1, l.tiles_per_chunk, l.ntiles, w.qpacked, ksteps, w.tau, p.qpad, w.seg_cnt,         \
+                       w.seg_ent, status)
+    switch (debug_mode()) {
+        case 2: ISC_LAUNCH_FILTER(2); break;
+        case 3: ISC_LAUNCH_FILTER(3); break;
+        default: ISC_LAUNCH_FILTER(0); break;
+    }
+#undef ISC_LAUNCH_FILTER
+}
+
 template <typename T>
 int run(const void* bank, int64_t n, int d, const void* queries, int q, int64_t ldq, int k, int64_t index_base,
         float* out_s, int64_t* out_i, int32_t* status, void* ws_base, hipStream_t stream) {
@@ -628,25 +684,14 @@ int run(const void* bank, int64_t n, int d, const void* queries, int q, int64_t 
     hipLaunchKernelGGL(k_init, dim3(isc_ceil_div(p.qpad, 256)), dim3(256), 0, stream, w.tau, w.carry_n, q, p.qpad,
                        status);
     hipLaunchKernelGGL(k_pack_queries<T>, dim3(isc_ceil_div(p.qpad * ksteps * 8, 256)), dim3(256), 0, stream,
-                       static_cast<const T*>(queries), ldq, q, d, ksteps, p.qpad, w.qpacked);
+                       static_cast<const T*>(queries), ldq, q, d, ksteps, p.qpad, p.tnq, w.qpacked);
     for (int level = 0;; ++level) {
         const Level l = make_level(level, n, p.qtiles);
         isc_timing_begin(ISC_KERNEL_DOTS_FILTER, stream);
-#define ISC_LAUNCH_FILTER(DBG_)                                                                                     \
-    hipLaunchKernelGGL((k_dots_filter<T, DBG_>), dim3(l.nchunks, p.qtiles), dim3(NTHREADS), 0, stream, bank_bytes,   \
-                       l.r0, l.r1, l.tiles_per_chunk, l.ntiles, w.qpacked, ksteps, w.tau, p.qpad, w.seg_cnt,         \
-                       w.seg_ent, status)
-        switch (debug_mode()) {
-            case 1: ISC_LAUNCH_FILTER(1); break;
-            case 2: ISC_LAUNCH_FILTER(2); break;
-            case 3: ISC_LAUNCH_FILTER(3); break;
-            case 4: ISC_LAUNCH_FILTER(4); break;
-            case 5: ISC_LAUNCH_FILTER(5); break;
-            default: ISC_LAUNCH_FILTER(0); break;
-        }
-#undef ISC_LAUNCH_FILTER
+        if (p.tnq == 256) launch_filter<T, 256>(l, p, w, bank_bytes, ksteps, status, stream);
+        else launch_filter<T, 64>(l, p, w, bank_bytes, ksteps, status, stream);
         isc_timing_end(ISC_KERNEL_DOTS_FILTER, stream);
-        hipLaunchKernelGGL(k_select, dim3(q), dim3(256), 0, stream, w.seg_cnt, w.seg_ent, SEGS_PER_CHUNK * l.nchunks,
+        hipLaunchKernelGGL(k_select, dim3(q), dim3(256), 0, stream, w.seg_cnt, w.seg_ent, p.segs_per_chunk * l.nchunks,
                            p.qpad, p.kp, w.tau, w.carry_s, w.carry_r, w.carry_n, status);
         if (l.r1 >= n) break;
     }
@@ -661,7 +706,7 @@ int check_args(int dtype, int64_t n, int d, int q, int k) {
     if (k > ISC_TOPK_MAX_K) return ISC_ERR_UNSUPPORTED;
     if (n > 0x7fffffff) return ISC_ERR_UNSUPPORTED;  // row ids are int32 inside a shard
     if (d > 65536) return ISC_ERR_UNSUPPORTED;
-    if (isc_ceil_div(q, TN) > 65535) return ISC_ERR_UNSUPPORTED;
+    if (isc_ceil_div(q, 64) > 65535) return ISC_ERR_UNSUPPORTED;
     return ISC_OK;
 }
 
