@@ -55,6 +55,7 @@ def parse_args() -> argparse.Namespace:
     ap.add_argument("--batch", type=int, default=512, help="encode batch (images per step per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the query-count sweep {1,16,64,256,1024} (N = 1 only)")
     return ap.parse_args()
 
 
@@ -112,6 +113,64 @@ def make_shard(lo: int, hi: int, dim: int, device: torch.device, seed: int) -> t
     return out
 
 
+def search_roofline(rows: int, d: int, q: int, k: int, kernel_ms_per_step: float, launches_per_step: float) -> dict:
+    """Roofline entry of k_dots_filter for one search step on one rank.  Algorithmic work:
+    every local bank row is read once (2 B / element) and dotted with every query."""
+    flops = 2.0 * q * rows * d
+    nbytes = rows * d * 2.0 + q * d * 2.0 + q * k * 12.0
+    sec = kernel_ms_per_step / 1e3
+    tflops = flops / sec / 1e12
+    gbs = nbytes / sec / 1e9
+    # arithmetic intensity ~ q flop/byte (fp16 bank): the MFMA roofline binds above ~310 queries, HBM below
+    ridge = MFMA_F16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    bound = "mfma" if flops / nbytes >= ridge else "hbm"
+    return {
+        "kernel": "k_dots_filter<f16>",
+        "bound": bound,
+        "achieved": round(tflops if bound == "mfma" else gbs, 2),
+        "peak": MFMA_F16_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
+        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+        "frac": round((tflops / MFMA_F16_PEAK_TFLOPS) if bound == "mfma" else (gbs / HBM_PEAK_GBS), 4),
+        "traffic": None,
+        "launches_per_step": launches_per_step,
+        "avg_launch_ms": round(kernel_ms_per_step / max(launches_per_step, 1e-9), 4),
+        "kernel_ms_per_step": round(kernel_ms_per_step, 4),
+        "algorithmic_flops_per_step": flops,
+        "algorithmic_bytes_per_step": nbytes,
+        "mfma_frac": round(tflops / MFMA_F16_PEAK_TFLOPS, 4),
+        "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+    }
+
+
+def query_sweep(bank: EmbeddingBank, rows: int, d: int, k: int, device: torch.device) -> list[dict]:
+    """the same bank searched with 1 .. 1024 queries, so that the HBM-bound regime
+    (few queries) is measured directly beside the MFMA-bound headline."""
+    out = []
+    for q in (1, 16, 64, 256, 1024):
+        queries = torch.randn((q, d), generator=torch.Generator().manual_seed(SEED + q)).half().to(device)
+        for _ in range(2):
+            bank.search(queries, k)
+        _lib.timing_enable(True)
+        _lib.timing_read(_lib.ISC_KERNEL_DOTS_FILTER)
+        steps = 5
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            bank.search(queries, k)
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / steps
+        kernel_ms, launches = _lib.timing_read(_lib.ISC_KERNEL_DOTS_FILTER)
+        _lib.timing_enable(False)
+        r = search_roofline(rows, d, q, k, kernel_ms / steps, launches / steps)
+        out.append({
+            "queries": q, "ms_per_search": round(sec * 1e3, 4), "queries_per_s": round(q / sec, 1),
+            "bank_gb_per_s_end_to_end": round(rows * d * 2.0 / sec / 1e9, 1),
+            "kernel_ms": r["kernel_ms_per_step"], "bound": r["bound"], "frac": r["frac"],
+            "mfma_frac": r["mfma_frac"], "hbm_frac": r["hbm_frac"],
+        })
+    return out
+
+
 def bench_search(args: argparse.Namespace, rank: int, world: int, device: torch.device) -> dict:
     n, d, q, k = args.bank_rows, args.dim, args.queries, args.k
     lo, hi = shard_bounds(n, world, rank)
@@ -133,34 +192,11 @@ def bench_search(args: argparse.Namespace, rank: int, world: int, device: torch.
     _lib.timing_enable(False)
     overflow = int(bank.last_status[0].item())
 
-    # algorithmic work of the dominant kernel (k_dots_filter), summed over its launches of one step on this rank:
-    # every local bank row is read once and dotted with every query
     rows = hi - lo
-    flops_per_step = 2.0 * q * rows * d
-    bytes_per_step = rows * d * 2.0 + q * d * 2.0 + q * k * 12.0
-    kernel_s_per_step = kernel_ms / 1e3 / args.steps
-    launches_per_step = launches / args.steps
-    tflops = flops_per_step / kernel_s_per_step / 1e12
-    gbs = bytes_per_step / kernel_s_per_step / 1e9
-    # arithmetic intensity ~ q flop/byte (fp16 bank): the MFMA roofline binds above ~310 queries, HBM below
-    ridge = MFMA_F16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-    bound = "mfma" if flops_per_step / bytes_per_step >= ridge else "hbm"
-    roofline = {
-        "kernel": "k_dots_filter<f16>",
-        "bound": bound,
-        "achieved": round(tflops if bound == "mfma" else gbs, 2),
-        "peak": MFMA_F16_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
-        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-        "frac": round((tflops / MFMA_F16_PEAK_TFLOPS) if bound == "mfma" else (gbs / HBM_PEAK_GBS), 4),
-        "traffic": None,
-        "launches_per_step": launches_per_step,
-        "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
-        "kernel_ms_per_step": round(kernel_s_per_step * 1e3, 4),
-        "algorithmic_flops_per_step": flops_per_step,
-        "algorithmic_bytes_per_step": bytes_per_step,
-        "mfma_frac": round(tflops / MFMA_F16_PEAK_TFLOPS, 4),
-        "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-    }
+    roofline = search_roofline(rows, d, q, k, kernel_ms / args.steps, launches / args.steps)
+    sweep = None
+    if world == 1 and not args.no_sweep:
+        sweep = query_sweep(bank, rows, d, k, device)
     return {
         "metric": "queries/s cosine top-10 over N x D bank",
         "value": round(q * args.steps / seconds, 1),
@@ -176,6 +212,7 @@ def bench_search(args: argparse.Namespace, rank: int, world: int, device: torch.
         },
         "roofline": roofline,
         "overflowed_candidate_buffers": overflow,
+        "q_sweep": sweep,
         "_bank": bank, "_queries": queries,
     }
 
@@ -318,6 +355,8 @@ def main() -> None:
         }
         if "overflowed_candidate_buffers" in primary:
             line["overflowed_candidate_buffers"] = primary["overflowed_candidate_buffers"]
+        if primary.get("q_sweep"):
+            line["q_sweep"] = primary["q_sweep"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_search(args) if args.workload == "search" else cpu_baseline_encode(args)
         if secondary is not None:
