@@ -67,12 +67,18 @@ def setup_dist(args: argparse.Namespace) -> tuple[int, int, torch.device]:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    device = torch.device("cuda", local)
+    # ISC_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("ISC_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
+
+
+def _collective_device(device: torch.device) -> torch.device:
+    return torch.device("cpu") if dist.get_backend() == "gloo" else device
 
 
 def fence(world: int) -> None:
@@ -85,7 +91,7 @@ def fence(world: int) -> None:
 def max_over_ranks(seconds: float, world: int, device: torch.device) -> float:
     if world == 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device=_collective_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

@@ -278,9 +278,12 @@ class EmbeddingBank:
         packed[..., 0] = part_s.view(torch.int32).to(torch.int64)
         packed[..., 1] = part_i
         # rank-major concatenation along dim 0 (the form both RCCL and gloo accept), viewed as [G, Q, k, 2]
-        gathered = torch.empty((self.world_size * nq, k, 2), dtype=torch.int64, device=part_s.device)
-        dist.all_gather_into_tensor(gathered, packed, group=self.process_group)
-        gathered = gathered.view(self.world_size, nq, k, 2)
+        # a gloo group exchanges host copies (used to rehearse the multi-rank path without RCCL)
+        on_host = dist.get_backend(self.process_group) == "gloo" and packed.device.type != "cpu"
+        src = packed.cpu() if on_host else packed
+        gathered = torch.empty((self.world_size * nq, k, 2), dtype=torch.int64, device=src.device)
+        dist.all_gather_into_tensor(gathered, src, group=self.process_group)
+        gathered = gathered.to(part_s.device).view(self.world_size, nq, k, 2)
         all_s = gathered[..., 0].to(torch.int32).view(torch.float32)
         all_i = gathered[..., 1].contiguous()
         return all_s.contiguous(), all_i
