@@ -8,7 +8,9 @@
 //                     compares its accumulators with a per-query threshold tau (the kp-th best score of the rows
 //                     seen in the earlier levels) and appends the few survivors (score, row) to a small
 //                     per-(segment, query) buffer.  Level 0 runs with tau = -inf.
-//     k_select        per query: survivors + the carried list -> the best kp by (score desc, row asc);
+//                     At its end every lane moves its survivors into a compact per-query list (one atomic per
+//                     lane and query block, outside the hot loop).
+//     k_select        one wave per query: survivors + the carried list -> the best kp by (score desc, row asc);
 //                     tau <- the kp-th score.
 //   k_rescore         the kp = k + slack carried candidates are re-scored EXACTLY (float64 dot, float64 query
 //                     norm), rounded to float32, ordered by (score desc, row asc); the first k are the result.
@@ -44,14 +46,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TM = 256;        // bank rows per tile
 constexpr int NTHREADS = 512;  // 8 waves
 constexpr int CAP = 32;        // candidate slots per (segment, query); segment = (chunk, row-block wave, lane group)
-constexpr int64_t LEVEL0_ROWS = 4096;
-constexpr int LEVEL_RATIO = 64;
+constexpr int64_t LEVEL0_ROWS = 4096;  // level 0: every score is a candidate (4096 per query)
+constexpr int LEVEL_RATIO = 64;       // each later level is 64x larger: ~kp * 64 = 1024 survivors per query
 constexpr int TARGET_WGS = 256;  // one workgroup per MI355X CU (the kernel uses all 160 KiB of LDS)
 constexpr int MAX_CHUNKS = 256;
-constexpr int SELECT_CAP = 4096;  // candidates one k_select workgroup can hold in LDS (level 0 produces 4096)
+constexpr int QCAP = 4096;  // survivors per query per level that the compact list / k_select can hold
 constexpr int SLACK = 6;
 constexpr int SMALL_Q = 128;  // up to this many queries the 64-query tile shape is used
-constexpr int MAX_SEG = 32 * MAX_CHUNKS;
 
 struct Cand {
     float s;
@@ -127,8 +128,9 @@ struct Workspace {
     float* carry_s;          // [qpad][kp]
     int32_t* carry_r;        // [qpad][kp]
     int32_t* carry_n;        // [qpad]
-    int32_t* seg_cnt;        // [max_seg][qpad]
-    Cand* seg_ent;           // [max_seg][qpad][CAP]
+    Cand* seg_ent;           // [max_seg][qpad][CAP]  lane-private survivor segments (written in the hot loop)
+    int32_t* qcount;         // [qpad]                survivors per query of the current level
+    Cand* qlist;             // [qpad][QCAP]          ... compacted at the end of k_dots_filter
     unsigned char* qpacked;  // [qtiles][ks][tnq][128 B]
     size_t bytes;
 };
@@ -145,18 +147,20 @@ Workspace carve(const Plan& p, int ks, void* base) {
     w.carry_s = static_cast<float*>(take((size_t)p.qpad * p.kp * 4));
     w.carry_r = static_cast<int32_t*>(take((size_t)p.qpad * p.kp * 4));
     w.carry_n = static_cast<int32_t*>(take((size_t)p.qpad * 4));
-    w.seg_cnt = static_cast<int32_t*>(take((size_t)p.max_seg * p.qpad * 4));
     w.seg_ent = static_cast<Cand*>(take((size_t)p.max_seg * p.qpad * CAP * sizeof(Cand)));
+    w.qcount = static_cast<int32_t*>(take((size_t)p.qpad * 4));
+    w.qlist = static_cast<Cand*>(take((size_t)p.qpad * QCAP * sizeof(Cand)));
     w.qpacked = static_cast<unsigned char*>(take((size_t)p.qpad * ks * ISC_KSTEP_BYTES));
     w.bytes = off;
     return w;
 }
 
-__global__ void k_init(float* tau, int32_t* carry_n, int q, int qpad, int32_t* status) {
+__global__ void k_init(float* tau, int32_t* carry_n, int32_t* qcount, int q, int qpad, int32_t* status) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < qpad) {
         tau[i] = i < q ? -INFINITY : INFINITY;  // padding queries never pass the filter
         carry_n[i] = 0;
+        qcount[i] = 0;
     }
     if (i < 4) status[i] = 0;
 }
@@ -192,16 +196,16 @@ template <>
 struct Mma<_Float16> {
     // acc[n] += A(16 rows) . B(16 queries x n) over the 64 halves of one K step.  One 16-byte chunk = 8 halves = the
     // k-slice one lane feeds to v_mfma_f32_16x16x32_f16; a0/b[0] hold chunks 0-3, a1/b[1] chunks 4-7.
+    static __device__ __forceinline__ void half(const u32x4& a, const u32x4 (&b)[4], f32x4 (&acc)[4]) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a),
+                                                            __builtin_bit_cast(half8, b[n]), acc[n], 0, 0, 0);
+    }
     static __device__ __forceinline__ void row(const u32x4& a0, const u32x4& a1, const u32x4 (&b)[2][4],
                                                f32x4 (&acc)[4]) {
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a0),
-                                                            __builtin_bit_cast(half8, b[0][n]), acc[n], 0, 0, 0);
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a1),
-                                                            __builtin_bit_cast(half8, b[1][n]), acc[n], 0, 0, 0);
+        half(a0, b[0], acc);
+        half(a1, b[1], acc);
     }
 };
 
@@ -210,19 +214,18 @@ struct Mma<float> {
     // one 16-byte chunk = 4 floats: element j of every lane's chunk goes to the j-th v_mfma_f32_16x16x4_f32.
     // Lane group g therefore supplies k = 4 * chunk + j instead of k = g: a permutation of the K axis applied
     // identically to both operands, which leaves the dot products unchanged.
+    static __device__ __forceinline__ void half(const u32x4& a, const u32x4 (&b)[4], f32x4 (&acc)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[n][j]), acc[n],
+                                                              0, 0, 0);
+    }
     static __device__ __forceinline__ void row(const u32x4& a0, const u32x4& a1, const u32x4 (&b)[2][4],
                                                f32x4 (&acc)[4]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a0[j]), __uint_as_float(b[0][n][j]),
-                                                              acc[n], 0, 0, 0);
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a1[j]), __uint_as_float(b[1][n][j]),
-                                                              acc[n], 0, 0, 0);
-        }
+        half(a0, b[0], acc);
+        half(a1, b[1], acc);
     }
 };
 
@@ -255,13 +258,14 @@ constexpr int A_TILE_BYTES = TM * 128;  // 32 KiB: one K step of one bank tile
 // read one iteration after the vmcnt + barrier that retires its DMA, and refilled one barrier after its last read.
 //
 // DBG is a bring-up aid (ISC_DEBUG_MODE environment variable, never set in production): 2 = no staging after the
-// prologue, 3 = staging but no MFMAs.  Results are wrong for DBG != 0.
+// prologue, 3 = staging but no MFMAs, 6 = like 2 without the per-step barrier, 7 = like 2 without LDS reads.  Results are wrong for DBG != 0.
 template <typename T, int TNQ, int DBG>
 __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* __restrict__ bank, int64_t r0,
                                                           int64_t r1, int tiles_per_chunk, int ntiles,
                                                           const unsigned char* __restrict__ qpacked, int ksteps,
                                                           const float* __restrict__ tau, int qpad,
-                                                          int32_t* __restrict__ seg_cnt, Cand* __restrict__ seg_ent,
+                                                          Cand* __restrict__ seg_ent, int32_t* __restrict__ qcount,
+                                                          Cand* __restrict__ qlist, int level0,
                                                           int32_t* __restrict__ status) {
     constexpr int WN = TNQ / 64;              // waves along the queries
     constexpr int WM = 8 / WN;                // waves along the bank rows
@@ -300,6 +304,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         thr[n] = tau[q0 + wn * 64 + n * 16 + frow];
+        if (DBG != 0) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
         cnt[n] = 0;
     }
 
@@ -332,15 +337,16 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     };
     // what iteration `it` issues (it < 0: prologue): first the query step, then the bank step
     auto issue_iter = [&](int it) {
-        if (DBG == 2 && it >= 0) return;
+        if ((DBG == 2 || DBG >= 6) && it >= 0) return;
         const int sb = it + DB, sa = it + DA;
         if (sb >= 0 && sb < total_steps) issue_b(sb);
         if (sa >= 0 && sa < total_steps) issue_a(sa);
     };
     // after iteration `next - 1` has issued: retire everything step `next` needs, leave the younger DMA in flight
     auto retire_for = [&](int next) {
-        if (DBG == 2) {
+        if (DBG == 2 || DBG >= 6) {
             wait_vmcnt<0>();
+            if (DBG == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             return;
         }
         if (TNQ == 256) {  // stream order ... B(next) A(next + 1): only A(next + 1) may stay in flight
@@ -378,6 +384,81 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 
     int kt = 0, tile = 0;
     for (int step = 0; step < total_steps; ++step) {
+        if constexpr (TNQ == 256 && DBG != 7) {
+            // ---- 256-query shape.  One K step = 8 row blocks of 8 MFMAs (fp16).  Fragment reads run two row blocks
+            // ahead of the matrix cores (LDS returns in order: lgkmcnt(4) = "all but the newest two blocks"), and the
+            // eight LDS-DMA instructions of this iteration are issued one per row block, so their issue cost hides
+            // behind MFMAs instead of delaying the first one.  DMA stream order (the counted vmcnt relies on it):
+            // the query step first, then the bank step.
+            const int sb = step + DB, sa = step + DA;
+            const bool do_b = DBG != 2 && DBG != 8 && sb < total_steps;
+            const bool do_a = DBG != 2 && DBG != 8 && sa < total_steps;
+            const unsigned char* bsrc = b_stream + (int64_t)(sb % ksteps) * B_TILE_BYTES;
+            unsigned char* bdst = lds_b + (sb % B_ST) * B_TILE_BYTES + wave_dst;
+            const unsigned char* asrc = a_stream + (int64_t)sa * A_TILE_BYTES;
+            unsigned char* adst = lds_a + (sa % A_ST) * A_TILE_BYTES + wave_dst;
+            const unsigned a_addr = lds_a_addr + (unsigned)((step % A_ST) * A_TILE_BYTES + a_wave_off);
+            const unsigned b_addr = lds_b_addr + (unsigned)((step % B_ST) * B_TILE_BYTES + b_wave_off);
+            const unsigned a_addr0 = a_addr + foff[0], a_addr1 = a_addr + foff[1];
+            const unsigned b_addr0 = b_addr + foff[0], b_addr1 = b_addr + foff[1];
+            u32x4 b0[4], b1[4], ar[3][2];
+            ISC_DS_READ(b0[0], b_addr0, 0);  // R0: what the first four MFMAs need
+            ISC_DS_READ(b0[1], b_addr0, 2048);
+            ISC_DS_READ(b0[2], b_addr0, 4096);
+            ISC_DS_READ(b0[3], b_addr0, 6144);
+            ISC_DS_READ(ar[0][0], a_addr0, 0);
+            ISC_DS_READ(b1[0], b_addr1, 0);  // R1
+            ISC_DS_READ(b1[1], b_addr1, 2048);
+            ISC_DS_READ(b1[2], b_addr1, 4096);
+            ISC_DS_READ(b1[3], b_addr1, 6144);
+            ISC_DS_READ(ar[0][1], a_addr1, 0);
+            ISC_DS_READ(ar[1][0], a_addr0, 2048);  // R2
+            ISC_DS_READ(ar[1][1], a_addr1, 2048);
+#define ISC_DMA(j_)                                                                 \
+    if ((j_) < 4) {                                                                 \
+        if (do_b) glds16(bsrc + 8192 * (j_), bdst + 8192 * (j_));                   \
+    } else {                                                                        \
+        if (do_a) glds16(asrc + 8192 * ((j_)-4), adst + 8192 * ((j_)-4));           \
+    }
+#define ISC_MFMA_HALF(a_, b_, m_)                                                                         \
+    if constexpr (DBG < 3) Mma<T>::half(a_, b_, acc[m_]);                                                 \
+    else acc[m_][0][0] += __uint_as_float((a_)[0] ^ (b_)[1][1] ^ (b_)[2][2]);
+            // row block 0: its two halves arrive separately
+            ISC_DS_READ(ar[2][0], a_addr0, 4096);  // R3
+            ISC_DS_READ(ar[2][1], a_addr1, 4096);
+            if constexpr (DBG == 8) asm volatile("" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(ar[0][0]));
+            else
+            asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(ar[0][0]));
+            __builtin_amdgcn_sched_barrier(0);
+            ISC_DMA(0)
+            ISC_MFMA_HALF(ar[0][0], b0, 0)
+            if constexpr (DBG == 8) asm volatile("" : "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]), "+v"(ar[0][1]));
+            else
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]), "+v"(ar[0][1]));
+            __builtin_amdgcn_sched_barrier(0);
+            ISC_MFMA_HALF(ar[0][1], b1, 0)
+#define ISC_ROW_BLOCK(m_, cur_, nxt_, wait_)                                                   \
+    if constexpr ((m_) + 2 < 8) {                                                              \
+        ISC_DS_READ(ar[nxt_][0], a_addr0, ((m_) + 2) * 2048);                                  \
+        ISC_DS_READ(ar[nxt_][1], a_addr1, ((m_) + 2) * 2048);                                  \
+    }                                                                                          \
+    if constexpr (DBG == 8) asm volatile("" : "+v"(ar[cur_][0]), "+v"(ar[cur_][1]));         \
+    else asm volatile("s_waitcnt lgkmcnt(" wait_ ")" : "+v"(ar[cur_][0]), "+v"(ar[cur_][1]));  \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    ISC_DMA(m_)                                                                                \
+    ISC_MFMA_HALF(ar[cur_][0], b0, m_)                                                         \
+    ISC_MFMA_HALF(ar[cur_][1], b1, m_)
+            ISC_ROW_BLOCK(1, 1, 0, "4")
+            ISC_ROW_BLOCK(2, 2, 1, "4")
+            ISC_ROW_BLOCK(3, 0, 2, "4")
+            ISC_ROW_BLOCK(4, 1, 0, "4")
+            ISC_ROW_BLOCK(5, 2, 1, "4")
+            ISC_ROW_BLOCK(6, 0, 2, "2")
+            ISC_ROW_BLOCK(7, 1, 0, "0")
+#undef ISC_ROW_BLOCK
+#undef ISC_MFMA_HALF
+#undef ISC_DMA
+        } else {
         issue_iter(step);
 
         // fragment reads and MFMAs, software pipelined per 16-row block: the reads of block m + 1 are in flight
@@ -388,6 +469,13 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             const unsigned a_addr0 = a_addr + foff[0], a_addr1 = a_addr + foff[1];
             const unsigned b_addr0 = b_addr + foff[0], b_addr1 = b_addr + foff[1];
             u32x4 bq[2][4], ar[2][2];
+            if constexpr (DBG == 7) {  // no LDS traffic: feed the matrix cores from whatever the registers hold
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bq[i >> 2][i & 3] = u32x4{(unsigned)step, 1u, 2u, (unsigned)lane};
+                ar[0][0] = ar[0][1] = ar[1][0] = ar[1][1] = u32x4{(unsigned)lane, 3u, (unsigned)step, 5u};
+#pragma unroll
+                for (int m = 0; m < MB; ++m) Mma<T>::row(ar[m & 1][0], ar[m & 1][1], bq, acc[m]);
+            } else {
             ISC_DS_READ(bq[0][0], b_addr0, 0);
             ISC_DS_READ(bq[0][1], b_addr0, 2048);
             ISC_DS_READ(bq[0][2], b_addr0, 4096);
@@ -427,6 +515,9 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             ISC_ROW_STEP(6, 0, 1)
             ISC_ROW_STEP(7, 1, 0)
 #undef ISC_ROW_STEP
+            }
+        }
+
         }
 
         if (++kt == ksteps) {
@@ -441,7 +532,19 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
                     mx = fmaxf(mx, fmaxf(fmaxf(acc[m][n][0], acc[m][n][1]), fmaxf(acc[m][n][2], acc[m][n][3])));
-                if (__ballot(mx >= thr[n]) != 0ull) {
+                if (level0) {
+                    // level 0 (tau = -inf, at most QCAP rows): every score is a survivor and goes straight to slot
+                    // `row` of the query's list -- no counters, no compaction
+                    Cand* dst = qlist + (size_t)(q0 + wn * 64 + n * 16 + frow) * QCAP;
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int64_t row = trow0 + m * 16 + r;
+                            const float s = acc[m][n][r];
+                            if (row < r1) dst[row - r0] = Cand{s == s ? s : -INFINITY, (int32_t)row};
+                        }
+                } else if (__ballot(mx >= thr[n]) != 0ull) {
 #pragma unroll
                     for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -465,14 +568,38 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
         // retire this wave's DMA for step + 1; the barrier then publishes every wave's pieces and guarantees nobody
         // still reads the slots refilled next iteration
         retire_for(step + 1);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (DBG != 6) __builtin_amdgcn_s_barrier();
     }
 
-    // publish this lane's survivor counts
+    // ---- tail: compact this lane's private survivors into the per-query list.  One returning atomic per
+    // (lane, query block) with survivors, outside the hot loop; the order inside a list is arbitrary, the
+    // selection that follows uses a total order.  Level 0 wrote the lists directly: only the count is set.
+    if (level0) {
+        if (chunk == 0 && wm == 0 && fg == 0) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) qcount[q0 + wn * 64 + n * 16 + frow] = (int)(r1 - r0);
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-        seg_cnt[(size_t)seg * qpad + q0 + wn * 64 + n * 16 + frow] = min(cnt[n], CAP);
+        const int c = min(cnt[n], CAP);
         if (cnt[n] > CAP) atomicAdd(&status[0], 1);
+        if (c > 0) {
+            const int q = q0 + wn * 64 + n * 16 + frow;
+            const int off = atomicAdd(&qcount[q], c);
+            const Cand* src = my_ent + (size_t)n * 16 * CAP;
+            Cand* dst = qlist + (size_t)q * QCAP;
+            if (off + c > QCAP) atomicAdd(&status[0], 1);
+            for (int i = 0; i < c; i += 4) {  // four independent loads per trip
+                Cand e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = src[min(i + j, c - 1)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i + j < c && off + i + j < QCAP) dst[off + i + j] = e[j];
+            }
+        }
     }
 }
 
@@ -483,121 +610,155 @@ __device__ __forceinline__ bool better(float sa, int ra, float sb, int rb) {
     return sa > sb || (sa == sb && ra < rb);
 }
 
-// One workgroup per query: gather the survivors of every segment plus the carried list, keep the best kp.
-__global__ __launch_bounds__(256) void k_select(const int32_t* __restrict__ seg_cnt, const Cand* __restrict__ seg_ent,
-                                                int nseg, int qpad, int kp, float* __restrict__ tau,
-                                                float* __restrict__ carry_s, int32_t* __restrict__ carry_r,
-                                                int32_t* __restrict__ carry_n, int32_t* __restrict__ status) {
-    __shared__ Cand cand[SELECT_CAP];
-    __shared__ int seg_off[MAX_SEG + 1];
-    __shared__ float red_s[4];
-    __shared__ int red_r[4], red_p[4];
-    __shared__ int wave_tot[4];
-    __shared__ int total_sh;
+// ---- selection ----------------------------------------------------------------------------------------------
+// (score, row) as one 64-bit key whose unsigned order is the search order: larger key = better candidate
+// (higher score first, then LOWER row).  Keys of distinct rows are distinct.  0 is "empty".
+__device__ __forceinline__ unsigned long long make_key(float s, int row) {
+    unsigned u = __float_as_uint(s);
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;  // monotone float -> unsigned
+    return ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - row);
+}
+__device__ __forceinline__ float key_score(unsigned long long k) {
+    unsigned u = (unsigned)(k >> 32);
+    u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ int key_row(unsigned long long k) { return 0x7fffffff - (int)(unsigned)(k & 0xffffffffu); }
+__device__ __forceinline__ unsigned long long bcast_key(unsigned long long k, int src_lane) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)k, src_lane);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(k >> 32), src_lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
 
-    const int q = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+// One WAVE per query: the level's survivors plus the carried list -> the best kp by (score desc, row asc),
+// tau <- the kp-th score.  Wave-synchronous, no workgroup barrier.
+//   1. every lane takes the maximum key of its strided share of the candidates;
+//   2. L = the kp-th largest of the 64 lane maxima: at least kp candidates are >= L, so the best kp all are;
+//   3. candidates >= L (typically ~1.3 kp of them) are compacted into LDS;
+//   4. if at most 64 remain they are ranked by 64 lane broadcasts, otherwise by repeated arg-max.
+constexpr int SEL_WAVES = 2;
+constexpr int SEL_SLACK = 8 * 64;  // the unrolled scans read up to this far past the end of the list
+__global__ __launch_bounds__(64 * SEL_WAVES) void k_select(int32_t* __restrict__ qcount, const Cand* __restrict__ qlist,
+                                                           int n_queries, int kp, float* __restrict__ tau,
+                                                           float* __restrict__ carry_s, int32_t* __restrict__ carry_r,
+                                                           int32_t* __restrict__ carry_n) {
+    __shared__ unsigned long long keys_all[SEL_WAVES][QCAP + 128 + SEL_SLACK];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * SEL_WAVES + wave;
+    if (q >= n_queries) return;
+    unsigned long long* keys = keys_all[wave];
+    // step 3 compacts IN PLACE: a trip loads its 512 keys into registers before it stores, and it only stores below
+    // the index it has read up to, so `surv` may alias `keys`
+    unsigned long long* surv = keys;
 
-    // exclusive scan of the segment counts: thread t owns segments [t * spt, (t + 1) * spt)
-    const int spt = (nseg + 255) / 256;
-    const int s_begin = tid * spt;
-    int v = 0;
-    for (int j = 0; j < spt; ++j) {
-        const int sidx = s_begin + j;
-        if (sidx < nseg) v += seg_cnt[(size_t)sidx * qpad + q];
-    }
-    int incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
-    int run = wbase + incl - v;
-    for (int j = 0; j < spt; ++j) {
-        const int sidx = s_begin + j;
-        if (sidx < nseg) {
-            seg_off[sidx] = run;
-            run += seg_cnt[(size_t)sidx * qpad + q];
-        }
-    }
+    const int from_list = min(qcount[q], QCAP);
     const int carried = carry_n[q];
-    if (tid == 255) {
-        seg_off[nseg] = wbase + incl;
-        total_sh = wbase + incl + carried;
+    const int total = from_list + carried;
+    const Cand* src = qlist + (size_t)q * QCAP;
+    for (int i0 = 0; i0 < from_list; i0 += 64 * 8) {  // eight independent coalesced loads per trip
+        Cand e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = src[min(i0 + 64 * j + lane, QCAP - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i0 + 64 * j + lane < from_list) keys[i0 + 64 * j + lane] = make_key(e[j].s, e[j].row);
     }
-    __syncthreads();
-    int total = total_sh;
-    const int from_segs = seg_off[nseg];
-    if (total > SELECT_CAP) {
-        if (tid == 0) atomicAdd(&status[0], 1);
-        total = SELECT_CAP;
-    }
-    // copy: thread t moves the (few) entries of its own segments
-    for (int j = 0; j < spt; ++j) {
-        const int sidx = s_begin + j;
-        if (sidx >= nseg) break;
-        const int o = seg_off[sidx];
-        const int c = seg_off[sidx + 1] - o;
-        const Cand* src = seg_ent + ((size_t)sidx * qpad + q) * CAP;
-        for (int i = 0; i < c; ++i)
-            if (o + i < SELECT_CAP) cand[o + i] = src[i];
-    }
-    for (int i = tid; i < carried; i += 256)
-        if (from_segs + i < SELECT_CAP) cand[from_segs + i] = Cand{carry_s[(size_t)q * kp + i], carry_r[(size_t)q * kp + i]};
-    __syncthreads();
+    for (int i = lane; i < carried; i += 64)
+        keys[from_list + i] = make_key(carry_s[(size_t)q * kp + i], carry_r[(size_t)q * kp + i]);
+    for (int i = total + lane; i < total + SEL_SLACK; i += 64) keys[i] = 0ull;  // padding reads as "empty"
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const int rounds = min(kp, total);
-    for (int r = 0; r < rounds; ++r) {
-        float bs = 0.f;
-        int br = -1, bp = -1;
-        for (int i = tid; i < total; i += 256) {
-            const Cand c = cand[i];
-            if (better(c.s, c.row, bs, br)) {
-                bs = c.s;
-                br = c.row;
-                bp = i;
-            }
-        }
+    // 1. lane maxima
+    unsigned long long lmax = 0ull;
+    for (int i0 = lane; i0 < total; i0 += 64 * 8) {
+        unsigned long long kk[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kk[j] = keys[i0 + 64 * j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lmax = kk[j] > lmax ? kk[j] : lmax;
+    }
+    // 2. threshold key: the kp-th largest lane maximum (0 = keep everything when kp > 64 or few lanes are filled)
+    unsigned long long lim = 0ull;
+    if (kp <= 64) {
+        int rank = 0;
+        for (int j = 0; j < 64; ++j) rank += bcast_key(lmax, j) > lmax ? 1 : 0;
+        // keys are distinct, except that several lanes may be empty (0): those never reach rank kp - 1 <= 63 ...
+        const unsigned long long mine = (rank == kp - 1) ? lmax : 0ull;
+        // ... so at most one lane contributes; OR-reduce it to every lane
+        unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const float os = __shfl_xor(bs, off, 64);
-            const int orow = __shfl_xor(br, off, 64);
-            const int op = __shfl_xor(bp, off, 64);
-            if (better(os, orow, bs, br)) {
-                bs = os;
-                br = orow;
-                bp = op;
+            lo |= __shfl_xor(lo, off, 64);
+            hi |= __shfl_xor(hi, off, 64);
+        }
+        lim = ((unsigned long long)hi << 32) | lo;
+    }
+    // 3. compact the candidates >= lim (empty slots are 0 and only pass when lim == 0; they are dropped explicitly)
+    int ns = 0;  // wave-uniform
+    for (int i0 = lane; i0 < total; i0 += 64 * 8) {
+        unsigned long long kk[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kk[j] = keys[i0 + 64 * j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool keep = kk[j] != 0ull && kk[j] >= lim;
+            const unsigned long long mask = __ballot(keep);
+            if (keep) surv[ns + __popcll(mask & ((1ull << lane) - 1ull))] = kk[j];
+            ns += __popcll(mask);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const int rounds = min(kp, ns);
+    if (ns <= 64) {
+        // 4a. rank the survivors: lane l holds survivor l, its rank is the number of larger keys
+        const unsigned long long mine = lane < ns ? surv[lane] : 0ull;
+        int rank = 0;
+        for (int j = 0; j < ns; ++j) rank += bcast_key(mine, j) > mine ? 1 : 0;
+        if (lane < ns && rank < kp) {
+            const float sc = key_score(mine);
+            carry_s[(size_t)q * kp + rank] = sc;
+            carry_r[(size_t)q * kp + rank] = key_row(mine);
+            if (rank == kp - 1) tau[q] = sc;
+        }
+    } else {
+        // 4b. many survivors (clustered scores, kp > 64): repeated arg-max below the previous winner
+        unsigned long long last = ~0ull;
+        for (int r = 0; r < rounds; ++r) {
+            unsigned long long best = 0ull;
+            for (int i = lane; i < ns; i += 64) {
+                const unsigned long long kx = surv[i];
+                if (kx < last && kx > best) best = kx;
+            }
+            unsigned lo = (unsigned)best, hi = (unsigned)(best >> 32);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned olo = __shfl_xor(lo, off, 64), ohi = __shfl_xor(hi, off, 64);
+                const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+                const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+                if (o > m) {
+                    lo = olo;
+                    hi = ohi;
+                }
+            }
+            last = ((unsigned long long)hi << 32) | lo;
+            if (lane == 0) {
+                const float sc = key_score(last);
+                carry_s[(size_t)q * kp + r] = sc;
+                carry_r[(size_t)q * kp + r] = key_row(last);
+                if (r == kp - 1) tau[q] = sc;
             }
         }
-        if (lane == 0) {
-            red_s[wave] = bs;
-            red_r[wave] = br;
-            red_p[wave] = bp;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            float ws = red_s[0];
-            int wr = red_r[0], wp = red_p[0];
-            for (int w = 1; w < 4; ++w)
-                if (better(red_s[w], red_r[w], ws, wr)) {
-                    ws = red_s[w];
-                    wr = red_r[w];
-                    wp = red_p[w];
-                }
-            carry_s[(size_t)q * kp + r] = ws;
-            carry_r[(size_t)q * kp + r] = wr;
-            if (wp >= 0) cand[wp].row = -1;  // taken
-            if (r == kp - 1) tau[q] = ws;
-        }
-        __syncthreads();
     }
-    if (tid == 0) carry_n[q] = rounds;
+    if (lane == 0) {
+        carry_n[q] = rounds;
+        qcount[q] = 0;  // ready for the next level
+    }
 }
 
 // One workgroup per query: exact float64 re-score of the carried candidates, final order, output.
@@ -664,11 +825,14 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
                    int32_t* status, hipStream_t stream) {
 #define ISC_LAUNCH_FILTER(DBG_)                                                                                      \
     hipLaunchKernelGGL((k_dots_filter<T, TNQ, DBG_>), dim3(l.nchunks, p.qtiles), dim3(NTHREADS), 0, stream, bank,    \
-                       l.r0, l.r1, l.tiles_per_chunk, l.ntiles, w.qpacked, ksteps, w.tau, p.qpad, w.seg_cnt,         \
-                       w.seg_ent, status)
+                       l.r0, l.r1, l.tiles_per_chunk, l.ntiles, w.qpacked, ksteps, w.tau, p.qpad, w.seg_ent,         \
+                       w.qcount, w.qlist, l.r0 == 0 ? 1 : 0, status)
     switch (debug_mode()) {
         case 2: ISC_LAUNCH_FILTER(2); break;
         case 3: ISC_LAUNCH_FILTER(3); break;
+        case 6: ISC_LAUNCH_FILTER(6); break;
+        case 7: ISC_LAUNCH_FILTER(7); break;
+        case 8: ISC_LAUNCH_FILTER(8); break;
         default: ISC_LAUNCH_FILTER(0); break;
     }
 #undef ISC_LAUNCH_FILTER
@@ -681,8 +845,8 @@ int run(const void* bank, int64_t n, int d, const void* queries, int q, int64_t 
     const int ksteps = isc_ksteps(d, (int)sizeof(T));
     const Workspace w = carve(p, ksteps, ws_base);
     const unsigned char* bank_bytes = static_cast<const unsigned char*>(bank);
-    hipLaunchKernelGGL(k_init, dim3(isc_ceil_div(p.qpad, 256)), dim3(256), 0, stream, w.tau, w.carry_n, q, p.qpad,
-                       status);
+    hipLaunchKernelGGL(k_init, dim3(isc_ceil_div(p.qpad, 256)), dim3(256), 0, stream, w.tau, w.carry_n, w.qcount, q,
+                       p.qpad, status);
     hipLaunchKernelGGL(k_pack_queries<T>, dim3(isc_ceil_div(p.qpad * ksteps * 8, 256)), dim3(256), 0, stream,
                        static_cast<const T*>(queries), ldq, q, d, ksteps, p.qpad, p.tnq, w.qpacked);
     for (int level = 0;; ++level) {
@@ -691,8 +855,8 @@ int run(const void* bank, int64_t n, int d, const void* queries, int q, int64_t 
         if (p.tnq == 256) launch_filter<T, 256>(l, p, w, bank_bytes, ksteps, status, stream);
         else launch_filter<T, 64>(l, p, w, bank_bytes, ksteps, status, stream);
         isc_timing_end(ISC_KERNEL_DOTS_FILTER, stream);
-        hipLaunchKernelGGL(k_select, dim3(q), dim3(256), 0, stream, w.seg_cnt, w.seg_ent, p.segs_per_chunk * l.nchunks,
-                           p.qpad, p.kp, w.tau, w.carry_s, w.carry_r, w.carry_n, status);
+        hipLaunchKernelGGL(k_select, dim3(isc_ceil_div(q, SEL_WAVES)), dim3(64 * SEL_WAVES), 0, stream, w.qcount, w.qlist,
+                           q, p.kp, w.tau, w.carry_s, w.carry_r, w.carry_n);
         if (l.r1 >= n) break;
     }
     hipLaunchKernelGGL(k_rescore<T>, dim3(q), dim3(256), 0, stream, bank_bytes, ksteps, static_cast<const T*>(queries),

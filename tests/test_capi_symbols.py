@@ -49,10 +49,10 @@ def test_host_only_entry_points(library: ctypes.CDLL) -> None:
     assert "workspace" in _lib.strerror(_lib.ISC_ERR_WORKSPACE)
     need = ctypes.c_size_t()
     assert lib.isc_cosine_topk_workspace_bytes(_lib.ISC_F16, 10_000_000, 768, 1024, 10, need) == 0
-    assert 100e6 < need.value < 200e6  # ~134 MiB of candidate segments
+    assert 100e6 < need.value < 250e6  # ~134 MiB of lane-private survivor segments + 32 MiB of per-query lists
     assert lib.isc_cosine_topk_workspace_bytes(_lib.ISC_F16, 256, 768, 1, 10, need) == 0
     small = need.value
-    assert small < 2e6
+    assert small < 8e6
     # k <= N; k <= ISC_TOPK_MAX_K; any D (the packed layout zero-pads the last K step)
     assert lib.isc_cosine_topk_workspace_bytes(_lib.ISC_F16, 1000, 100, 4, 10, need) == 0
     assert lib.isc_bank_packed_bytes(_lib.ISC_F16, 10_000_000, 768, need) == 0
