@@ -258,7 +258,7 @@ constexpr int A_TILE_BYTES = TM * 128;  // 32 KiB: one K step of one bank tile
 // read one iteration after the vmcnt + barrier that retires its DMA, and refilled one barrier after its last read.
 //
 // DBG is a bring-up aid (ISC_DEBUG_MODE environment variable, never set in production): 2 = no staging after the
-// prologue, 3 = staging but no MFMAs, 6 = like 2 without the per-step barrier, 7 = like 2 without LDS reads.  Results are wrong for DBG != 0.
+// prologue, 3 = staging but no MFMAs, 7 = like 2 without LDS fragment reads.  The filter never fires then.  Results are wrong for DBG != 0.
 template <typename T, int TNQ, int DBG>
 __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* __restrict__ bank, int64_t r0,
                                                           int64_t r1, int tiles_per_chunk, int ntiles,
@@ -337,16 +337,15 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     };
     // what iteration `it` issues (it < 0: prologue): first the query step, then the bank step
     auto issue_iter = [&](int it) {
-        if ((DBG == 2 || DBG >= 6) && it >= 0) return;
+        if ((DBG == 2 || DBG == 7) && it >= 0) return;
         const int sb = it + DB, sa = it + DA;
         if (sb >= 0 && sb < total_steps) issue_b(sb);
         if (sa >= 0 && sa < total_steps) issue_a(sa);
     };
     // after iteration `next - 1` has issued: retire everything step `next` needs, leave the younger DMA in flight
     auto retire_for = [&](int next) {
-        if (DBG == 2 || DBG >= 6) {
+        if (DBG == 2 || DBG == 7) {
             wait_vmcnt<0>();
-            if (DBG == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             return;
         }
         if (TNQ == 256) {  // stream order ... B(next) A(next + 1): only A(next + 1) may stay in flight
@@ -391,8 +390,8 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             // behind MFMAs instead of delaying the first one.  DMA stream order (the counted vmcnt relies on it):
             // the query step first, then the bank step.
             const int sb = step + DB, sa = step + DA;
-            const bool do_b = DBG != 2 && DBG != 8 && sb < total_steps;
-            const bool do_a = DBG != 2 && DBG != 8 && sa < total_steps;
+            const bool do_b = DBG != 2 && sb < total_steps;
+            const bool do_a = DBG != 2 && sa < total_steps;
             const unsigned char* bsrc = b_stream + (int64_t)(sb % ksteps) * B_TILE_BYTES;
             unsigned char* bdst = lds_b + (sb % B_ST) * B_TILE_BYTES + wave_dst;
             const unsigned char* asrc = a_stream + (int64_t)sa * A_TILE_BYTES;
@@ -421,19 +420,15 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
         if (do_a) glds16(asrc + 8192 * ((j_)-4), adst + 8192 * ((j_)-4));           \
     }
 #define ISC_MFMA_HALF(a_, b_, m_)                                                                         \
-    if constexpr (DBG < 3) Mma<T>::half(a_, b_, acc[m_]);                                                 \
+    if constexpr (DBG != 3) Mma<T>::half(a_, b_, acc[m_]);                                                 \
     else acc[m_][0][0] += __uint_as_float((a_)[0] ^ (b_)[1][1] ^ (b_)[2][2]);
             // row block 0: its two halves arrive separately
             ISC_DS_READ(ar[2][0], a_addr0, 4096);  // R3
             ISC_DS_READ(ar[2][1], a_addr1, 4096);
-            if constexpr (DBG == 8) asm volatile("" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(ar[0][0]));
-            else
             asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(ar[0][0]));
             __builtin_amdgcn_sched_barrier(0);
             ISC_DMA(0)
             ISC_MFMA_HALF(ar[0][0], b0, 0)
-            if constexpr (DBG == 8) asm volatile("" : "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]), "+v"(ar[0][1]));
-            else
             asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]), "+v"(ar[0][1]));
             __builtin_amdgcn_sched_barrier(0);
             ISC_MFMA_HALF(ar[0][1], b1, 0)
@@ -442,8 +437,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
         ISC_DS_READ(ar[nxt_][0], a_addr0, ((m_) + 2) * 2048);                                  \
         ISC_DS_READ(ar[nxt_][1], a_addr1, ((m_) + 2) * 2048);                                  \
     }                                                                                          \
-    if constexpr (DBG == 8) asm volatile("" : "+v"(ar[cur_][0]), "+v"(ar[cur_][1]));         \
-    else asm volatile("s_waitcnt lgkmcnt(" wait_ ")" : "+v"(ar[cur_][0]), "+v"(ar[cur_][1]));  \
+    asm volatile("s_waitcnt lgkmcnt(" wait_ ")" : "+v"(ar[cur_][0]), "+v"(ar[cur_][1]));       \
     __builtin_amdgcn_sched_barrier(0);                                                         \
     ISC_DMA(m_)                                                                                \
     ISC_MFMA_HALF(ar[cur_][0], b0, m_)                                                         \
@@ -501,7 +495,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
         else                                                                                                         \
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[cur_][0]), "+v"(ar[cur_][1]));                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if constexpr (DBG < 3)                                                                                       \
+        if constexpr (DBG != 3)                                                                                      \
             Mma<T>::row(ar[cur_][0], ar[cur_][1], bq, acc[m_]);                                                      \
         else                                                                                                         \
             acc[m_][0][0] += __uint_as_float(ar[cur_][0][0] ^ ar[cur_][1][1] ^ bq[0][1][0] ^ bq[1][2][1]);           \
@@ -568,7 +562,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
         // retire this wave's DMA for step + 1; the barrier then publishes every wave's pieces and guarantees nobody
         // still reads the slots refilled next iteration
         retire_for(step + 1);
-        if constexpr (DBG != 6) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
     }
 
     // ---- tail: compact this lane's private survivors into the per-query list.  One returning atomic per
@@ -830,9 +824,7 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
     switch (debug_mode()) {
         case 2: ISC_LAUNCH_FILTER(2); break;
         case 3: ISC_LAUNCH_FILTER(3); break;
-        case 6: ISC_LAUNCH_FILTER(6); break;
         case 7: ISC_LAUNCH_FILTER(7); break;
-        case 8: ISC_LAUNCH_FILTER(8); break;
         default: ISC_LAUNCH_FILTER(0); break;
     }
 #undef ISC_LAUNCH_FILTER

@@ -42,7 +42,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // TCO output channels x TPIX pixels per workgroup of 4 waves; every wave owns a 64 x 64 sub-tile.
-template <int TCO, int TPIX>
+// TAP4 = the small-Cin mode of the stem: Cin == 4 (RGB + one zero channel), a K step is 8 filter taps x 4 channels,
+// weights are [Cout][ceil(R*S/8)*8 taps][4] with the padding taps zero.
+template <int TCO, int TPIX, bool TAP4>
 __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
     constexpr int WCO = TCO / 64;          // waves along the output channels
     constexpr int NA = TCO * 8 / 256;      // 16-byte staging slots per thread, weight tile
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
             const int rem = m - b * p.Ho * p.Wo;
             const int ho = rem / p.Wo;
             const int wo = rem - ho * p.Wo;
-            b_base[i] = b * p.H * p.W * p.Cin + lchunk * 4;
+            b_base[i] = b * p.H * p.W * p.Cin + (TAP4 ? 0 : lchunk * 4);
             b_hw0[i] = ((ho * p.stride - p.pad) << 16) | ((wo * p.stride - p.pad) & 0xffff);
         } else {
             b_base[i] = 0;
@@ -96,30 +98,62 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) foff[cc] = frow * 128 + (((cc * 4 + fg) ^ fsw) << 4);
 
+    // The accumulators start as bias + residual (issued first, so these loads fly while the first K step is staged):
+    // the epilogue is then only the activation and the store.  16x16 MFMA result layout: column (pixel) = lane & 15,
+    // rows (channels) = 4 * (lane >> 4) + 0..3.
     f32x4 acc[4][4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int ni = 0; ni < 4; ++ni) {
+        const int m = pix0 + wpix * 64 + ni * 16 + (lane & 15);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < 4; ++mi) {
+            const int co = co0 + wco * 64 + mi * 16 + (lane >> 4) * 4;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < p.M && co < p.Cout) {
+                if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + co);
+                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
+            }
+            acc[mi][ni] = v;
+        }
+    }
 
     u32x4 sa[NA], sb[NB];
 
     auto load_step = [&](int ks) {
-        const int rs = ks / p.cin_steps;
-        const int c0 = (ks - rs * p.cin_steps) * 32;
-        const int r = rs / p.S;
-        const int s = rs - r * p.S;
-        const int koff = rs * p.Cin + c0;
+        if constexpr (TAP4) {
+            // this thread's 16-byte chunk is one filter tap (4 channels): tap = 8 * ks + logical chunk
+            const int tap = ks * 8 + lchunk;
+            const int r = tap / p.S;
+            const int s = tap - r * p.S;
+            const bool tap_ok = tap < p.R * p.S;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) sa[i] = *reinterpret_cast<const u32x4*>(p.w + (size_t)(a_off[i] + koff));
+            for (int i = 0; i < NA; ++i) sa[i] = *reinterpret_cast<const u32x4*>(p.w + (size_t)(a_off[i] + ks * 32));
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int hi = (b_hw0[i] >> 16) + r;
-            const int wi = (int)(short)(b_hw0[i] & 0xffff) + s;
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (ok) v = *reinterpret_cast<const u32x4*>(p.x + (size_t)(b_base[i] + (hi * p.W + wi) * p.Cin + c0));
-            sb[i] = v;
+            for (int i = 0; i < NB; ++i) {
+                const int hi = (b_hw0[i] >> 16) + r;
+                const int wi = (int)(short)(b_hw0[i] & 0xffff) + s;
+                const bool ok = tap_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (ok) v = *reinterpret_cast<const u32x4*>(p.x + (size_t)(b_base[i] + (hi * p.W + wi) * 4));
+                sb[i] = v;
+            }
+        } else {
+            const int rs = ks / p.cin_steps;
+            const int c0 = (ks - rs * p.cin_steps) * 32;
+            const int r = rs / p.S;
+            const int s = rs - r * p.S;
+            const int koff = rs * p.Cin + c0;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) sa[i] = *reinterpret_cast<const u32x4*>(p.w + (size_t)(a_off[i] + koff));
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int hi = (b_hw0[i] >> 16) + r;
+                const int wi = (int)(short)(b_hw0[i] & 0xffff) + s;
+                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (ok) v = *reinterpret_cast<const u32x4*>(p.x + (size_t)(b_base[i] + (hi * p.W + wi) * p.Cin + c0));
+                sb[i] = v;
+            }
         }
     };
     auto store_step = [&](int buf) {
@@ -163,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue.  16x16 MFMA result: column (pixel) = lane & 15, rows (channels) = 4 * (lane >> 4) + 0..3
+    // ---- epilogue: activation and one 16-byte store per (pixel, four channels)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const int m = pix0 + wpix * 64 + ni * 16 + frow;
@@ -173,12 +207,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
             const int co = co0 + wco * 64 + mi * 16 + fg * 4;
             if (co >= p.Cout) continue;  // Cout % 4 == 0, so a lane's four channels are in or out together
             f32x4 v = acc[mi][ni];
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
-            const size_t o = (size_t)m * p.Cout + co;
-            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
-            *reinterpret_cast<f32x4*>(p.out + o) = v;
+            *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.Cout + co) = v;
         }
     }
 }
@@ -274,13 +305,15 @@ extern "C" int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, con
     ISC_REQUIRE(x && w && out);
     ISC_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0);
     ISC_REQUIRE(act == ISC_ACT_NONE || act == ISC_ACT_RELU || act == ISC_ACT_GELU);
-    if (Cin % 32 != 0 || Cout % 4 != 0) return ISC_ERR_UNSUPPORTED;  // pad channels with zeros
+    const bool tap4 = Cin == 4;  // stem mode: w is [Cout][ceil(R*S/8)*8][4]
+    if ((!tap4 && Cin % 32 != 0) || Cout % 4 != 0) return ISC_ERR_UNSUPPORTED;  // pad channels with zeros
     if (H > 16384 || W > 16384 || pad > 8192) return ISC_ERR_UNSUPPORTED;
     const int Ho = (H + 2 * pad - R) / stride + 1;
     const int Wo = (W + 2 * pad - S) / stride + 1;
     ISC_REQUIRE(Ho > 0 && Wo > 0);
     const int64_t M = (int64_t)B * Ho * Wo;
-    const int64_t K = (int64_t)R * S * Cin;
+    const int ksteps = tap4 ? isc_ceil_div(R * S, 8) : R * S * (Cin / 32);
+    const int64_t K = (int64_t)ksteps * 32;
     if ((int64_t)B * H * W * Cin >= (1ll << 31) || M * Cout >= (1ll << 31) || (int64_t)Cout * K >= (1ll << 31))
         return ISC_ERR_UNSUPPORTED;  // 32-bit element offsets inside the kernel
     if (!isc_aligned(x, 16) || !isc_aligned(w, 16) || !isc_aligned(out, 16) || (bias && !isc_aligned(bias, 16)) ||
@@ -289,17 +322,18 @@ extern "C" int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, con
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.res = residual; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
-    p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = Cin / 32; p.ksteps = R * S * (Cin / 32); p.act = act;
+    p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = tap4 ? 1 : Cin / 32; p.ksteps = ksteps; p.act = act;
     hipStream_t s = isc_stream(stream);
     const bool narrow = Cout <= 64;
     const int64_t blocks = narrow ? isc_ceil_div(Cout, 64) * isc_ceil_div<int64_t>(M, 256)
                                   : isc_ceil_div(Cout, 128) * isc_ceil_div<int64_t>(M, 128);
     if (blocks > 0x7fffffff) return ISC_ERR_UNSUPPORTED;
     isc_timing_begin(ISC_KERNEL_CONV, s);
-    if (narrow)
-        hipLaunchKernelGGL((k_conv_f32<64, 256>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL((k_conv_f32<128, 128>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    const dim3 grid((unsigned)blocks), block(256);
+    if (narrow && tap4) hipLaunchKernelGGL((k_conv_f32<64, 256, true>), grid, block, 0, s, p);
+    else if (narrow) hipLaunchKernelGGL((k_conv_f32<64, 256, false>), grid, block, 0, s, p);
+    else if (tap4) hipLaunchKernelGGL((k_conv_f32<128, 128, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((k_conv_f32<128, 128, false>), grid, block, 0, s, p);
     isc_timing_end(ISC_KERNEL_CONV, s);
     return isc_launch_status();
 }

@@ -192,7 +192,7 @@ class ResNet50Embedder(EmbeddingModule):
         b, _c, h, w = x.shape
         ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
         # the kernels index with 32-bit element offsets: bound the images per pass
-        per_image = max(ho * wo * resnet50.STEM_KPAD, 1)
+        per_image = max(ho * wo * 256, 1)
         chunk = max(1, min(b, (2**31 - 1) // per_image))
         out = torch.empty((b, self._embedding_dim), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
@@ -206,13 +206,16 @@ class ResNet50Embedder(EmbeddingModule):
         net = self._net
         b, c, h, w = x.shape
         ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
-        kpad = resnet50.STEM_KPAD
-        patches = torch.empty((b, ho, wo, kpad), dtype=torch.float32, device=x.device)
-        _lib.check(lib.isc_im2col_nchw(x.data_ptr(), b, c, h, w, 7, 7, 2, 3, kpad, patches.data_ptr(), stream),
-                   "isc_im2col_nchw")
-        stem = resnet50.FoldedConv(net.stem.weight, net.stem.bias, 1, 1, 0)  # a 1x1 conv over the patch rows
-        y = _conv(patches, stem, _lib.ISC_ACT_RELU)
-        del patches
+        # stem: NCHW -> NHWC with a zero fourth channel, then the 7x7 / 2 convolution in the kernel's "stem mode"
+        x4 = torch.empty((b, h, w, 4), dtype=torch.float32, device=x.device)
+        _lib.check(lib.isc_nchw_to_nhwc(x.data_ptr(), b, c, h, w, 4, x4.data_ptr(), stream), "isc_nchw_to_nhwc")
+        y = torch.empty((b, ho, wo, 64), dtype=torch.float32, device=x.device)
+        st = lib.isc_conv2d_nhwc(
+            x4.data_ptr(), b, h, w, 4, net.stem.weight.data_ptr(), 64, 7, 7, 2, 3, net.stem.bias.data_ptr(), None,
+            _lib.ISC_ACT_RELU, y.data_ptr(), stream,
+        )
+        _lib.check(st, "isc_conv2d_nhwc (stem)")
+        del x4
         hp, wp = (ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1
         pooled = torch.empty((b, hp, wp, 64), dtype=torch.float32, device=x.device)
         _lib.check(lib.isc_maxpool_nhwc(y.data_ptr(), b, ho, wo, 64, 3, 2, 1, pooled.data_ptr(), stream),

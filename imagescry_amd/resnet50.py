@@ -18,7 +18,7 @@ from torch import Tensor
 STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))  # (bottleneck width, blocks, stride of first block)
 EXPANSION = 4
 BN_EPS = 1e-5
-STEM_KPAD = 160  # 7 * 7 * 3 = 147 padded to a multiple of the 32-channel K step
+STEM_TAPS = 56  # 7 * 7 = 49 filter taps padded to a multiple of 8 (one K step of the stem = 8 taps x 4 channels)
 
 
 def _kaiming_normal_fan_out(shape: tuple[int, int, int, int], g: torch.Generator) -> Tensor:
@@ -111,7 +111,7 @@ class Bottleneck:
 
 @dataclass
 class FoldedResNet50:
-    stem: FoldedConv  # weight [64, STEM_KPAD]
+    stem: FoldedConv  # weight [64, STEM_TAPS, 4]: taps (r, s) x (R, G, B, 0)
     blocks: list[Bottleneck]
     fc: FoldedConv  # weight [E, 1, 1, 2048]
 
@@ -121,8 +121,8 @@ class FoldedResNet50:
 
 def fold_state_dict(sd: dict[str, Tensor]) -> FoldedResNet50:
     stem = fold_conv_bn(sd, "conv1", "bn1", stride=2, pad=3)
-    w = stem.weight.reshape(stem.weight.shape[0], -1)  # [64, 7*7*3], K ordered (r, s, c)
-    stem.weight = torch.nn.functional.pad(w, (0, STEM_KPAD - w.shape[1])).contiguous()
+    w = stem.weight.reshape(stem.weight.shape[0], 49, 3)  # [64, taps (r, s), c]
+    stem.weight = torch.nn.functional.pad(w, (0, 1, 0, STEM_TAPS - 49)).contiguous()  # channel 3 and taps 49.. are zero
     blocks: list[Bottleneck] = []
     for li, (_planes, nblocks, stride) in enumerate(STAGES, start=1):
         for bi in range(nblocks):

@@ -129,8 +129,8 @@ int isc_nchw_to_nhwc(const float* x, int B, int C, int H, int W, int Cpad, float
 /* out = act(conv2d(x, w) + bias [+ residual]) as an implicit GEMM on the f32 matrix cores.
  * The build's stand-in for the torchvision backbone the reference calls at
  * src/imagescry/models/embedding.py:167-177 (BatchNorm folded into w / bias by the host).
- *   x        float [B,H,W,Cin]         NHWC, Cin % 32 == 0... see ISC_ERR_UNSUPPORTED
- *   w        float [Cout,R,S,Cin]      KRSC
+ *   x        float [B,H,W,Cin]         NHWC, Cin % 32 == 0 -- or Cin == 4 ("stem mode", RGB + one zero channel)
+ *   w        float [Cout,R,S,Cin]      KRSC; in stem mode [Cout, ceil(R*S/8)*8, 4] with the padding taps zero
  *   bias     float [Cout] or NULL
  *   residual float [B,Ho,Wo,Cout] or NULL (added before the activation)
  *   out      float [B,Ho,Wo,Cout],  Ho = (H + 2*pad - R)/stride + 1 (same for Wo)

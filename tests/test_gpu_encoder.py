@@ -70,6 +70,33 @@ def test_conv2d_nhwc(b, h, w, cin, cout, k, stride, pad, epilogue, device: torch
     assert _rel_err(got, exp) < 1e-5
 
 
+@pytest.mark.parametrize("b,h,w,cout,k,stride,pad", [(2, 37, 29, 64, 7, 2, 3), (1, 16, 16, 128, 3, 1, 1), (3, 9, 20, 64, 5, 2, 2)])
+def test_conv2d_stem_mode(b, h, w, cout, k, stride, pad, device: torch.device) -> None:
+    """Cin == 4 (RGB + zero channel): a K step is eight filter taps; weights [Cout, ceil(k*k/8)*8, 4]."""
+    from imagescry_amd import _lib
+
+    g = cases.gen(b + h + cout)
+    x = torch.randn(b, 3, h, w, generator=g)
+    wt = torch.randn(cout, 3, k, k, generator=g) / (3 * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    exp = F.relu(F.conv2d(x, wt, bias, stride=stride, padding=pad))
+    taps = (k * k + 7) // 8 * 8
+    wk = torch.zeros(cout, taps, 4)
+    wk[:, : k * k, :3] = wt.permute(0, 2, 3, 1).reshape(cout, k * k, 3)
+    lib = _lib.load()
+    xd = x.to(device)
+    x4 = torch.empty((b, h, w, 4), device=device)
+    stream = _lib.stream_handle(device)
+    _lib.check(lib.isc_nchw_to_nhwc(xd.data_ptr(), b, 3, h, w, 4, x4.data_ptr(), stream), "nchw_to_nhwc")
+    ho, wo = exp.shape[-2:]
+    out = torch.empty((b, ho, wo, cout), device=device)
+    wd, bd = wk.to(device), bias.to(device)
+    st = lib.isc_conv2d_nhwc(x4.data_ptr(), b, h, w, 4, wd.data_ptr(), cout, k, k, stride, pad, bd.data_ptr(), None,
+                             _lib.ISC_ACT_RELU, out.data_ptr(), stream)
+    _lib.check(st, "isc_conv2d_nhwc")
+    assert _rel_err(out.permute(0, 3, 1, 2).cpu(), exp) < 1e-5
+
+
 def test_im2col_maxpool_avgpool(device: torch.device) -> None:
     from imagescry_amd import _lib
 

@@ -113,11 +113,13 @@ def test_bn_folding_and_krsc_layout_match_the_unfused_oracle() -> None:
     got = F.conv2d(x, w, blk.conv2.bias, stride=blk.conv2.stride, padding=blk.conv2.pad)
     exp = encoder_oracle._bn(F.conv2d(x, sd["layer1.0.conv2.weight"], padding=1), sd, "layer1.0.bn2")
     assert torch.allclose(got, exp, rtol=1e-4, atol=1e-5)
-    # stem: [64, 160] rows ordered (r, s, c), zero padded
+    # stem: [64, 56 taps, 4 channels], taps ordered (r, s); channel 3 and taps 49..55 are zero padding
     img = torch.randn(1, 3, 20, 20, generator=g)
     cols = F.unfold(img, 7, stride=2, padding=3).reshape(1, 3, 49, -1).permute(0, 3, 2, 1).reshape(-1, 147)
-    got = (cols @ net.stem.weight[:, :147].T + net.stem.bias).T.reshape(1, 64, 10, 10)
+    assert net.stem.weight.shape == (64, resnet50.STEM_TAPS, 4)
+    w147 = net.stem.weight[:, :49, :3].reshape(64, 147)
+    got = (cols @ w147.T + net.stem.bias).T.reshape(1, 64, 10, 10)
     exp = encoder_oracle._bn(F.conv2d(img, sd["conv1.weight"], stride=2, padding=3), sd, "bn1")
     assert torch.allclose(got, exp, rtol=1e-4, atol=1e-5)
-    assert float(net.stem.weight[:, 147:].abs().max()) == 0.0
+    assert float(net.stem.weight[:, 49:].abs().max()) == 0.0 and float(net.stem.weight[:, :, 3].abs().max()) == 0.0
     assert len(net.blocks) == 16 and sum(b.downsample is not None for b in net.blocks) == 4
