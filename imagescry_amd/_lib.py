@@ -66,6 +66,9 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
         [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
          c_void_p, c_void_p],
     ),
+    "isc_linear_centered": (
+        c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+    ),
     "isc_im2col_nchw": (
         c_int,
         [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],

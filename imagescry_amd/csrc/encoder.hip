@@ -26,6 +26,7 @@ struct ConvParams {
     const float* w;
     const float* bias;
     const float* res;
+    const float* sub;  // optional per-input-channel vector subtracted from x before the product (PCA centring)
     float* out;
     int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo;
     int M;          // B * Ho * Wo output pixels
@@ -151,7 +152,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
                 const int wi = (int)(short)(b_hw0[i] & 0xffff) + s;
                 const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                if (ok) v = *reinterpret_cast<const u32x4*>(p.x + (size_t)(b_base[i] + (hi * p.W + wi) * p.Cin + c0));
+                if (ok) {
+                    v = *reinterpret_cast<const u32x4*>(p.x + (size_t)(b_base[i] + (hi * p.W + wi) * p.Cin + c0));
+                    if (p.sub) {  // (x - mean) first, then the product: the order the reference uses
+                        const f32x4 mu = *reinterpret_cast<const f32x4*>(p.sub + c0 + lchunk * 4);
+                        v = __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, v) - mu);
+                    }
+                }
                 sb[i] = v;
             }
         }
@@ -299,9 +306,9 @@ int stream_grid(size_t items) {
 
 }  // namespace
 
-extern "C" int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S,
-                               int stride, int pad, const float* bias, const float* residual, int act, float* out,
-                               void* stream) {
+static int conv_launch(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S, int stride,
+                       int pad, const float* bias, const float* residual, const float* sub, int act, float* out,
+                       void* stream) {
     ISC_REQUIRE(x && w && out);
     ISC_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0);
     ISC_REQUIRE(act == ISC_ACT_NONE || act == ISC_ACT_RELU || act == ISC_ACT_GELU);
@@ -320,7 +327,7 @@ extern "C" int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, con
         (residual && !isc_aligned(residual, 16)))
         return ISC_ERR_ALIGNMENT;
     ConvParams p;
-    p.x = x; p.w = w; p.bias = bias; p.res = residual; p.out = out;
+    p.x = x; p.w = w; p.bias = bias; p.res = residual; p.sub = sub; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = tap4 ? 1 : Cin / 32; p.ksteps = ksteps; p.act = act;
     hipStream_t s = isc_stream(stream);
@@ -336,6 +343,19 @@ extern "C" int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, con
     else hipLaunchKernelGGL((k_conv_f32<128, 128, false>), grid, block, 0, s, p);
     isc_timing_end(ISC_KERNEL_CONV, s);
     return isc_launch_status();
+}
+
+extern "C" int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S,
+                               int stride, int pad, const float* bias, const float* residual, int act, float* out,
+                               void* stream) {
+    return conv_launch(x, B, H, W, Cin, w, Cout, R, S, stride, pad, bias, residual, nullptr, act, out, stream);
+}
+
+extern "C" int isc_linear_centered(const float* x, int64_t n, int F, const float* mean, const float* w, int K,
+                                   const float* bias, float* out, void* stream) {
+    ISC_REQUIRE(n > 0 && n < (1ll << 31));
+    if (mean && !isc_aligned(mean, 16)) return ISC_ERR_ALIGNMENT;
+    return conv_launch(x, (int)n, 1, 1, F, w, K, 1, 1, 1, 0, bias, nullptr, mean, ISC_ACT_NONE, out, stream);
 }
 
 extern "C" int isc_nchw_to_nhwc(const float* x, int B, int C, int H, int W, int Cpad, float* y, void* stream) {

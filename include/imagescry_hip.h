@@ -138,6 +138,12 @@ int isc_nchw_to_nhwc(const float* x, int B, int C, int H, int W, int Cpad, float
 int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S, int stride,
                     int pad, const float* bias, const float* residual, int act, float* out, void* stream);
 
+/* out[n, K] = (x[n, F] - mean[F]) . w[K, F]^T + bias[K]   (mean and bias may be NULL; F % 32 == 0, K % 4 == 0).
+ * The centring happens before the product, as in `torch.matmul(x - feature_means, component_vectors)` of
+ * reference src/imagescry/models/decomposition.py:91 (`PCA.forward`); w is `component_vectors` transposed. */
+int isc_linear_centered(const float* x, int64_t n, int F, const float* mean, const float* w, int K, const float* bias,
+                        float* out, void* stream);
+
 /* im2col for the stem convolution (small Cin): x NCHW float [B,C,H,W] -> patches float [B*Ho*Wo, Kpad] with the K axis
  * ordered (r, s, c) and zero-padded from R*S*C to Kpad. */
 int isc_im2col_nchw(const float* x, int B, int C, int H, int W, int R, int S, int stride, int pad, int Kpad, float* y,
