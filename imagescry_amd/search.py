@@ -20,6 +20,7 @@ depend on G.
 from __future__ import annotations
 
 import math
+from os import PathLike
 from typing import Sequence
 
 import torch
@@ -90,6 +91,7 @@ class EmbeddingBank:
         self._bank = self._store(embeddings, normalize)
         self._workspaces: dict[tuple[int, int], Tensor] = {}
         self.last_status: Tensor | None = None
+        self.row_origin: Tensor | None = None  # set by from_database: (image_id, h, w) of every row
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -103,6 +105,27 @@ class EmbeddingBank:
         rows = torch.cat([b.get_flat_vectors() for b in batches], dim=0)
         kwargs.setdefault("normalize", False)
         return cls(rows, **kwargs)  # type: ignore[arg-type]
+
+    @classmethod
+    def from_database(
+        cls,
+        db: "str | PathLike",
+        *,
+        device: str | torch.device = "cuda",
+        image_ids: Sequence[int] | None = None,
+        **kwargs: object,
+    ) -> "EmbeddingBank":
+        """Bank built from the reference's SQLite store (`<dir>/imagescry.db`, table `embeddings`): every spatial
+        location of every stored `[C, H, W]` map becomes one row, in (record, h, w) order.  `row_origin`
+        (`int64 [N, 3]` = image_id, h, w) maps result indices back to images.  Stored maps are PCA-compressed,
+        i.e. not unit length, so rows are L2-normalised unless `normalize=False` is passed.
+        (reference format: storage/models.py:73-129; read order: storage/operations.py:108-144)"""
+        from imagescry_amd import storage
+
+        rows, origin = storage.flat_rows(storage.read_embeddings(db, image_ids=image_ids))
+        bank = cls(rows.to(device), **kwargs)  # type: ignore[arg-type]
+        bank.row_origin = origin
+        return bank
 
     def _store(self, embeddings: Tensor, normalize: bool) -> Tensor:
         """Row-normalise / cast the rows and write them into the PACKED bank image (`isc_bank_pack`):

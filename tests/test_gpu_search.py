@@ -223,3 +223,23 @@ def test_full_size_properties(dtype: torch.dtype, device: torch.device) -> None:
         better += (blk > kth[:, None]).sum(dim=1)
     assert bool((better <= k - 1).all())
     assert bool((better == (scores.double() > kth[:, None]).sum(dim=1)).all())
+
+
+def test_bank_from_reference_database(tmp_path, device: torch.device) -> None:
+    """N2: a bank built from the reference's SQLite `embeddings` table answers like the oracle on the same rows."""
+    from imagescry_amd import EmbeddingBank, storage
+
+    g = cases.gen(12)
+    maps = [torch.randn(96, 2, 3, generator=g), torch.randn(96, 1, 2, generator=g), torch.randn(96, 3, 3, generator=g)]
+    storage.write_embeddings(tmp_path, [(5, maps[0]), (6, maps[1]), (9, maps[2])])
+    bank = EmbeddingBank.from_database(tmp_path, device=device, dtype=torch.float32)
+    rows = torch.cat([m.permute(1, 2, 0).reshape(-1, 96) for m in maps])
+    assert len(bank) == 17 and bank.row_origin.shape == (17, 3)
+    stored = bank.bank.cpu()
+    assert torch.allclose(stored, search_oracle.l2_normalize_rows(rows), atol=1e-6)
+    queries = rows[[3, 7, 16]] + 0.01 * torch.randn(3, 96, generator=g)
+    exp_s, exp_i = search_oracle.cosine_topk(stored, queries, 5)
+    scores, indices = bank.search(queries.to(device), 5)
+    _check(scores, indices, exp_s, exp_i)
+    assert indices[:, 0].cpu().tolist() == [3, 7, 16]
+    assert bank.row_origin[indices[2, 0].item()].tolist() == [9, 2, 2]
