@@ -12,6 +12,7 @@ All arithmetic runs in hand-written HIP kernels behind the C ABI of include/imag
 PyTorch is used for device memory, streams and `torch.distributed` only.
 """
 
+from imagescry_amd.batching import ImageTensorDataset, SimilarShapeBatcher
 from imagescry_amd.data import EmbeddingBatch, ImageBatch
 from imagescry_amd.decomposition import PCA
 from imagescry_amd.embedding import EmbeddingModule, ResNet50Embedder, l2_normalize_channels
@@ -28,6 +29,8 @@ __all__ = [
     "ResNet50Embedder",
     "l2_normalize_channels",
     "ImageBatch",
+    "ImageTensorDataset",
+    "SimilarShapeBatcher",
     "normalize_per_channel",
     "resize",
     "shard_bounds",
