@@ -18,7 +18,8 @@ LIB_NAME = "libimagescry_hip.so"
 LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
 
 ISC_U8, ISC_F16, ISC_F32 = 0, 1, 2
-ISC_ACT_NONE, ISC_ACT_RELU, ISC_ACT_GELU = 0, 1, 2
+ISC_ACT_NONE, ISC_ACT_RELU, ISC_ACT_GELU, ISC_ACT_SILU, ISC_ACT_SIGMOID = 0, 1, 2, 3, 4
+ISC_ACT_RESIDUAL_AFTER = 0x100
 ISC_TOPK_MAX_K = 120
 ISC_KERNEL_DOTS_FILTER, ISC_KERNEL_CONV = 0, 1
 
@@ -65,6 +66,15 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
         c_int,
         [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
          c_void_p, c_void_p],
+    ),
+    "isc_conv2d_nhwc_gated": (
+        c_int,
+        [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+         c_void_p, c_int, c_void_p, c_void_p],
+    ),
+    "isc_dwconv2d_nhwc": (
+        c_int,
+        [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
     ),
     "isc_linear_centered": (
         c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]

@@ -26,7 +26,8 @@ struct ConvParams {
     const float* w;
     const float* bias;
     const float* res;
-    const float* sub;  // optional per-input-channel vector subtracted from x before the product (PCA centring)
+    const float* sub;    // optional per-input-channel vector subtracted from x before the product (PCA centring)
+    const float* scale;  // optional [B, Cin] factor applied to x before the product (squeeze-excitation gate)
     float* out;
     int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo;
     int M;          // B * Ho * Wo output pixels
@@ -34,11 +35,14 @@ struct ConvParams {
     int cin_steps;  // Cin / 32
     int ksteps;     // R * S * cin_steps
     int act;
+    int res_after_act;  // out = act(conv + bias) + residual instead of act(conv + bias + residual)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ISC_ACT_RELU) return fmaxf(v, 0.f);
     if (act == ISC_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (act == ISC_ACT_SILU) return __fdiv_rn(v, 1.f + expf(-v));
+    if (act == ISC_ACT_SIGMOID) return __fdiv_rn(1.f, 1.f + expf(-v));
     return v;
 }
 
@@ -73,6 +77,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) a_off[i] = min(co0 + srow + 32 * i, p.Cout - 1) * p.K + lchunk * 4;
 
+    int b_img[NB];   // image index (for the optional per-image input scale)
     int b_base[NB];  // element offset of image b
     int b_hw0[NB];   // (ho * stride - pad) << 16 | (wo * stride - pad) & 0xffff ; rows past M are pushed out of range
 #pragma unroll
@@ -83,9 +88,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
             const int rem = m - b * p.Ho * p.Wo;
             const int ho = rem / p.Wo;
             const int wo = rem - ho * p.Wo;
+            b_img[i] = b;
             b_base[i] = b * p.H * p.W * p.Cin + (TAP4 ? 0 : lchunk * 4);
             b_hw0[i] = ((ho * p.stride - p.pad) << 16) | ((wo * p.stride - p.pad) & 0xffff);
         } else {
+            b_img[i] = 0;
             b_base[i] = 0;
             b_hw0[i] = (int)0x80008000;  // hi0 = wi0 = -32768: never inside the image
         }
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (m < p.M && co < p.Cout) {
                 if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + co);
-                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
+                if (p.res && !p.res_after_act) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
             }
             acc[mi][ni] = v;
         }
@@ -157,6 +164,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
                     if (p.sub) {  // (x - mean) first, then the product: the order the reference uses
                         const f32x4 mu = *reinterpret_cast<const f32x4*>(p.sub + c0 + lchunk * 4);
                         v = __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, v) - mu);
+                    }
+                    if (p.scale) {
+                        const f32x4 g = *reinterpret_cast<const f32x4*>(p.scale + (size_t)b_img[i] * p.Cin + c0 + lchunk * 4);
+                        v = __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, v) * g);
                     }
                 }
                 sb[i] = v;
@@ -216,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
             f32x4 v = acc[mi][ni];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+            if (p.res && p.res_after_act) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
             *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.Cout + co) = v;
         }
     }
@@ -287,6 +299,37 @@ __global__ __launch_bounds__(256) void k_maxpool_nhwc(const float* __restrict__ 
     }
 }
 
+// depthwise R x R convolution, NHWC, weights [R][R][C]: one thread = four channels of one output pixel
+__global__ __launch_bounds__(256) void k_dwconv_nhwc(const float* __restrict__ x, int H, int W, int C, int R, int stride,
+                                                     int pad, int Ho, int Wo, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, int act, size_t total4,
+                                                     float* __restrict__ y) {
+    const int cvec = C / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int cv = (int)(i % cvec);
+        const size_t m = i / cvec;
+        const int b = (int)(m / ((size_t)Ho * Wo));
+        const int rem = (int)(m - (size_t)b * Ho * Wo);
+        const int ho = rem / Wo, wo = rem - ho * Wo;
+        f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + cv * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < R; ++r) {
+            const int hi = ho * stride + r - pad;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int s = 0; s < R; ++s) {
+                const int wi = wo * stride + s - pad;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + hi) * W + wi) * C + cv * 4);
+                const f32x4 k = *reinterpret_cast<const f32x4*>(w + ((size_t)r * R + s) * C + cv * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(v[j], k[j], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = apply_act(acc[j], act);
+        *reinterpret_cast<f32x4*>(y + i * 4) = acc;
+    }
+}
+
 // grid (ceil(C / 256), B): thread = one channel, loop over the HW positions (coalesced across channels)
 __global__ __launch_bounds__(256) void k_global_avgpool_nhwc(const float* __restrict__ x, int HW, int C,
                                                              float* __restrict__ y) {
@@ -307,11 +350,14 @@ int stream_grid(size_t items) {
 }  // namespace
 
 static int conv_launch(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S, int stride,
-                       int pad, const float* bias, const float* residual, const float* sub, int act, float* out,
-                       void* stream) {
+                       int pad, const float* bias, const float* residual, const float* sub, const float* scale, int act,
+                       float* out, void* stream) {
     ISC_REQUIRE(x && w && out);
     ISC_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0);
-    ISC_REQUIRE(act == ISC_ACT_NONE || act == ISC_ACT_RELU || act == ISC_ACT_GELU);
+    const int res_after_act = (act & ISC_ACT_RESIDUAL_AFTER) ? 1 : 0;
+    act &= ~ISC_ACT_RESIDUAL_AFTER;
+    ISC_REQUIRE(act >= ISC_ACT_NONE && act <= ISC_ACT_SIGMOID);
+    if (scale && (Cin == 4 || !isc_aligned(scale, 16))) return ISC_ERR_UNSUPPORTED;
     const bool tap4 = Cin == 4;  // stem mode: w is [Cout][ceil(R*S/8)*8][4]
     if ((!tap4 && Cin % 32 != 0) || Cout % 4 != 0) return ISC_ERR_UNSUPPORTED;  // pad channels with zeros
     if (H > 16384 || W > 16384 || pad > 8192) return ISC_ERR_UNSUPPORTED;
@@ -327,9 +373,9 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
         (residual && !isc_aligned(residual, 16)))
         return ISC_ERR_ALIGNMENT;
     ConvParams p;
-    p.x = x; p.w = w; p.bias = bias; p.res = residual; p.sub = sub; p.out = out;
+    p.x = x; p.w = w; p.bias = bias; p.res = residual; p.sub = sub; p.scale = scale; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
-    p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = tap4 ? 1 : Cin / 32; p.ksteps = ksteps; p.act = act;
+    p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = tap4 ? 1 : Cin / 32; p.ksteps = ksteps; p.act = act; p.res_after_act = res_after_act;
     hipStream_t s = isc_stream(stream);
     const bool narrow = Cout <= 64;
     const int64_t blocks = narrow ? isc_ceil_div(Cout, 64) * isc_ceil_div<int64_t>(M, 256)
@@ -348,14 +394,21 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
 extern "C" int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S,
                                int stride, int pad, const float* bias, const float* residual, int act, float* out,
                                void* stream) {
-    return conv_launch(x, B, H, W, Cin, w, Cout, R, S, stride, pad, bias, residual, nullptr, act, out, stream);
+    return conv_launch(x, B, H, W, Cin, w, Cout, R, S, stride, pad, bias, residual, nullptr, nullptr, act, out, stream);
+}
+
+extern "C" int isc_conv2d_nhwc_gated(const float* x, int B, int H, int W, int Cin, const float* gate, const float* w,
+                                     int Cout, int R, int S, int stride, int pad, const float* bias,
+                                     const float* residual, int act, float* out, void* stream) {
+    ISC_REQUIRE(gate);
+    return conv_launch(x, B, H, W, Cin, w, Cout, R, S, stride, pad, bias, residual, nullptr, gate, act, out, stream);
 }
 
 extern "C" int isc_linear_centered(const float* x, int64_t n, int F, const float* mean, const float* w, int K,
                                    const float* bias, float* out, void* stream) {
     ISC_REQUIRE(n > 0 && n < (1ll << 31));
     if (mean && !isc_aligned(mean, 16)) return ISC_ERR_ALIGNMENT;
-    return conv_launch(x, (int)n, 1, 1, F, w, K, 1, 1, 1, 0, bias, nullptr, mean, ISC_ACT_NONE, out, stream);
+    return conv_launch(x, (int)n, 1, 1, F, w, K, 1, 1, 1, 0, bias, nullptr, mean, nullptr, ISC_ACT_NONE, out, stream);
 }
 
 extern "C" int isc_nchw_to_nhwc(const float* x, int B, int C, int H, int W, int Cpad, float* y, void* stream) {
@@ -391,6 +444,22 @@ extern "C" int isc_maxpool_nhwc(const float* x, int B, int H, int W, int C, int 
     const size_t total4 = (size_t)B * Ho * Wo * (C / 4);
     hipLaunchKernelGGL(k_maxpool_nhwc, dim3(stream_grid(total4)), dim3(256), 0, isc_stream(stream), x, H, W, C, R, stride,
                        pad, Ho, Wo, total4, y);
+    return isc_launch_status();
+}
+
+extern "C" int isc_dwconv2d_nhwc(const float* x, int B, int H, int W, int C, const float* w, int R, int stride, int pad,
+                                 const float* bias, int act, float* y, void* stream) {
+    ISC_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && R > 0 && stride > 0 && pad >= 0);
+    ISC_REQUIRE(act >= ISC_ACT_NONE && act <= ISC_ACT_SIGMOID);
+    if (C % 4 != 0) return ISC_ERR_UNSUPPORTED;
+    if (!isc_aligned(x, 16) || !isc_aligned(w, 16) || !isc_aligned(y, 16) || (bias && !isc_aligned(bias, 16)))
+        return ISC_ERR_ALIGNMENT;
+    const int Ho = (H + 2 * pad - R) / stride + 1;
+    const int Wo = (W + 2 * pad - R) / stride + 1;
+    ISC_REQUIRE(Ho > 0 && Wo > 0);
+    const size_t total4 = (size_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(k_dwconv_nhwc, dim3(stream_grid(total4)), dim3(256), 0, isc_stream(stream), x, H, W, C, R, stride,
+                       pad, Ho, Wo, w, bias, act, total4, y);
     return isc_launch_status();
 }
 

@@ -15,11 +15,11 @@ from typing import Iterable
 import torch
 from torch import Tensor
 
-from imagescry_amd import _lib, resnet50
+from imagescry_amd import _lib, efficientnet, resnet50
 from imagescry_amd.data import EmbeddingBatch, ImageBatch
 from imagescry_amd.transforms import normalize_per_channel, resize
 
-__all__ = ["EmbeddingModule", "ResNet50Embedder", "l2_normalize_channels"]
+__all__ = ["EfficientNetEmbedder", "EmbeddingModule", "ResNet50Embedder", "l2_normalize_channels"]
 
 
 def l2_normalize_channels(x: Tensor, eps: float = 1e-12) -> Tensor:
@@ -27,12 +27,23 @@ def l2_normalize_channels(x: Tensor, eps: float = 1e-12) -> Tensor:
     if x.ndim != 4 or x.dtype != torch.float32:
         raise ValueError(f"expected a float32 [B, E, H, W] tensor, got {x.dtype} {tuple(x.shape)}")
     _lib.require_device(x, "x")
+    b, e, h, w = x.shape
+    lib = _lib.load()
+    nhwc = x.permute(0, 2, 3, 1)
+    if not x.is_contiguous() and nhwc.is_contiguous():
+        # a channels-last buffer seen through an NCHW view (what the NHWC encoders hand back): every location is a
+        # contiguous row of E channels -- normalise the rows in place of a layout change
+        y = torch.empty_like(nhwc)
+        if x.numel():
+            with torch.cuda.device(x.device):
+                st = lib.isc_l2norm_channels(nhwc.data_ptr(), b * h * w, e, 1, eps, y.data_ptr(),
+                                             _lib.stream_handle(x.device))
+            _lib.check(st, "isc_l2norm_channels")
+        return y.permute(0, 3, 1, 2)
     x = x.contiguous()
     y = torch.empty_like(x)
-    b, e, h, w = x.shape
     if x.numel() == 0:
         return y
-    lib = _lib.load()
     with torch.cuda.device(x.device):
         st = lib.isc_l2norm_channels(x.data_ptr(), b, e, h * w, eps, y.data_ptr(), _lib.stream_handle(x.device))
     _lib.check(st, "isc_l2norm_channels")
@@ -231,3 +242,77 @@ class ResNet50Embedder(EmbeddingModule):
         _lib.check(lib.isc_global_avgpool_nhwc(y.data_ptr(), bb, hh, ww, cc, feat.data_ptr(), stream),
                    "isc_global_avgpool_nhwc")
         return _conv(feat, net.fc, _lib.ISC_ACT_NONE).reshape(bb, self._embedding_dim)
+
+
+class EfficientNetEmbedder(EmbeddingModule):
+    """Embedding model using EfficientNetV2 as the backbone feature extractor -- the reference's concrete embedder
+    (src/imagescry/models/embedding.py:108-183), same constructor, same output geometry
+    `[B, 1280, ceil(H/32), ceil(W/32)]` (one embedding vector per 32 x 32 pixel cell).
+
+    `pretrained=True` needs the torchvision weight download (embedding.py:135-141), which this offline build cannot
+    perform; pass a torchvision `features` state dict through `state_dict` instead.
+    """
+
+    def __init__(
+        self,
+        *,
+        backbone_size: str = "s",
+        max_side_length: int = 640,
+        pretrained: bool = False,
+        state_dict: dict[str, Tensor] | None = None,
+        seed: int = 0,
+    ) -> None:
+        super().__init__()
+        if backbone_size not in efficientnet.STAGES:
+            raise ValueError(f"Invalid model size: {backbone_size}")
+        if pretrained and state_dict is None:
+            raise RuntimeError(
+                "pretrained weights must be downloaded (EfficientNet_V2_*_Weights.DEFAULT) and there is no network here; "
+                "pass the torchvision `features` state dict via `state_dict=`"
+            )
+        self._embedding_dim = efficientnet.LAST_CHANNELS
+        self.backbone_size = backbone_size
+        self.max_side_length = max_side_length
+        self.hparams = {"backbone_size": backbone_size, "max_side_length": max_side_length}
+        sd = state_dict if state_dict is not None else efficientnet.make_state_dict(backbone_size, seed=seed)
+        self._net = efficientnet.fold_state_dict(sd, backbone_size)
+
+    def _move(self, device: torch.device) -> None:
+        self._net = self._net.to(device)
+
+    @property
+    def embedding_dim(self) -> int:
+        return self._embedding_dim
+
+    def preprocess(self, images: Tensor) -> Tensor:
+        """reference: embedding.py:149-165."""
+        if not isinstance(images, Tensor) or images.dtype != torch.uint8:
+            raise TypeError("images must be a uint8 tensor")
+        if images.ndim != 4:
+            raise ValueError(f"images must have shape [B, C, H, W], got {tuple(images.shape)}")
+        h, w = images.shape[-2:]
+        if max(h, w) > self.max_side_length:
+            images = resize(images, output_size=self.max_side_length, side_ref="long")
+        return normalize_per_channel(images, min_value=-3, max_value=3)
+
+    def forward(self, x: Tensor) -> Tensor:
+        """float32 `[B, 3, H, W]` -> float32 `[B, 1280, ceil(H/32), ceil(W/32)]` (an NCHW view of the kernels'
+        channels-last result; reference: embedding.py:167-177)."""
+        if not isinstance(x, Tensor) or x.dtype != torch.float32:
+            raise TypeError("x must be a float32 tensor")
+        if x.ndim != 4 or x.shape[1] != 3:
+            raise ValueError(f"x must have shape [B, 3, H, W], got {tuple(x.shape)}")
+        _lib.require_device(x, "x")
+        if self.device != x.device:
+            raise ValueError(f"module is on {self.device} but the input is on {x.device}; call .to() first")
+        x = x.contiguous()
+        b, _c, h, w = x.shape
+        ho, wo = (h + 1) // 2, (w + 1) // 2
+        per_image = max(ho * wo * 256, 1)  # largest activation of one image, in elements (32-bit kernel offsets)
+        chunk = max(1, min(b, (2**31 - 1) // per_image))
+        outs = []
+        with torch.cuda.device(x.device):
+            for b0 in range(0, b, chunk):
+                outs.append(efficientnet.forward_features(self._net, x[b0 : b0 + chunk]))
+        y = outs[0] if len(outs) == 1 else torch.cat(outs)
+        return y.permute(0, 3, 1, 2)

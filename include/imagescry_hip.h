@@ -49,6 +49,9 @@ extern "C" {
 #define ISC_ACT_NONE 0
 #define ISC_ACT_RELU 1
 #define ISC_ACT_GELU 2 /* exact erf form */
+#define ISC_ACT_SILU 3    /* x * sigmoid(x) */
+#define ISC_ACT_SIGMOID 4
+#define ISC_ACT_RESIDUAL_AFTER 0x100 /* OR into `act`: out = act(conv + bias) + residual (default: residual inside act) */
 
 int isc_abi_version(void);
 const char* isc_strerror(int status);
@@ -137,6 +140,18 @@ int isc_nchw_to_nhwc(const float* x, int B, int C, int H, int W, int Cpad, float
  * A linear layer is the case H=W=R=S=1. */
 int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S, int stride,
                     int pad, const float* bias, const float* residual, int act, float* out, void* stream);
+
+/* Same as isc_conv2d_nhwc with the input first multiplied by a per-(image, input channel) gate float [B, Cin]:
+ * the squeeze-excitation scale of an MBConv block fused into its 1x1 projection convolution. */
+int isc_conv2d_nhwc_gated(const float* x, int B, int H, int W, int Cin, const float* gate, const float* w, int Cout, int R,
+                          int S, int stride, int pad, const float* bias, const float* residual, int act, float* out,
+                          void* stream);
+
+/* Depthwise R x R convolution (groups == channels), NHWC float, weights float [R,R,C], bias float [C] or NULL,
+ * C % 4 == 0: y = act(dwconv(x, w) + bias).  The depthwise stage of torchvision's MBConv block, which the reference
+ * runs inside `efficientnet_v2_*.features` (src/imagescry/models/embedding.py:133-147). */
+int isc_dwconv2d_nhwc(const float* x, int B, int H, int W, int C, const float* w, int R, int stride, int pad,
+                      const float* bias, int act, float* y, void* stream);
 
 /* out[n, K] = (x[n, F] - mean[F]) . w[K, F]^T + bias[K]   (mean and bias may be NULL; F % 32 == 0, K % 4 == 0).
  * The centring happens before the product, as in `torch.matmul(x - feature_means, component_vectors)` of

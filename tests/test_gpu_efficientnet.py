@@ -1,0 +1,142 @@
+"""EfficientNetV2 feature extractor on the GPU against the oracle, and the
+reference's own encoder test (tests/test_models/test_embedding.py:78-106: output shape for 27 input geometries)."""
+
+from __future__ import annotations
+
+import math
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
+import cases  # noqa: E402
+
+from oracle import efficientnet_oracle, encoder_oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _stages(size: str):
+    from imagescry_amd import efficientnet
+
+    return [[(b.kind, b.expand, b.stride, b.cin, b.cout) for b in stage] for stage in efficientnet.block_specs(size)]
+
+
+def test_depthwise_and_gated_conv_kernels(device: torch.device) -> None:
+    from imagescry_amd import _lib
+
+    lib = _lib.load()
+    stream = _lib.stream_handle(device)
+    g = cases.gen(3)
+    for stride, h, w, c in ((1, 9, 11, 96), (2, 14, 14, 256), (2, 7, 5, 32)):
+        x = torch.randn(2, c, h, w, generator=g)
+        wt = torch.randn(c, 1, 3, 3, generator=g) * 0.3
+        bias = torch.randn(c, generator=g)
+        exp = F.silu(F.conv2d(x, wt, bias, stride=stride, padding=1, groups=c))
+        xd = x.permute(0, 2, 3, 1).contiguous().to(device)
+        wd = wt[:, 0].permute(1, 2, 0).contiguous().to(device)
+        bd = bias.to(device)
+        out = torch.empty((2, exp.shape[2], exp.shape[3], c), device=device)
+        st = lib.isc_dwconv2d_nhwc(xd.data_ptr(), 2, h, w, c, wd.data_ptr(), 3, stride, 1, bd.data_ptr(), _lib.ISC_ACT_SILU,
+                                   out.data_ptr(), stream)
+        _lib.check(st, "isc_dwconv2d_nhwc")
+        np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+    # gated 1x1 projection with residual: out = conv(x * gate) + bias + res
+    x = torch.randn(3, 64, 6, 5, generator=g)
+    gate = torch.sigmoid(torch.randn(3, 64, generator=g))
+    wt = torch.randn(32, 64, 1, 1, generator=g) * 0.2
+    bias = torch.randn(32, generator=g)
+    res = torch.randn(3, 32, 6, 5, generator=g)
+    exp = F.conv2d(x * gate[:, :, None, None], wt, bias) + res
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device)
+    out = torch.empty((3, 6, 5, 32), device=device)
+    gd, wd, bd = gate.to(device), wt.permute(0, 2, 3, 1).contiguous().to(device), bias.to(device)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(device)
+    st = lib.isc_conv2d_nhwc_gated(xd.data_ptr(), 3, 6, 5, 64, gd.data_ptr(), wd.data_ptr(), 32, 1, 1, 1, 0, bd.data_ptr(),
+                                   rd.data_ptr(), _lib.ISC_ACT_NONE, out.data_ptr(), stream)
+    _lib.check(st, "isc_conv2d_nhwc_gated")
+    np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+    # residual added after the activation (expand == 1 FusedMBConv)
+    exp = F.silu(F.conv2d(x, wt, bias)) + res
+    st = lib.isc_conv2d_nhwc(xd.data_ptr(), 3, 6, 5, 64, wd.data_ptr(), 32, 1, 1, 1, 0, bd.data_ptr(), rd.data_ptr(),
+                             _lib.ISC_ACT_SILU | _lib.ISC_ACT_RESIDUAL_AFTER, out.data_ptr(), stream)
+    _lib.check(st, "isc_conv2d_nhwc")
+    np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 3, 35, 42)])
+def test_efficientnet_s_forward_matches_oracle(shape: tuple[int, ...], device: torch.device) -> None:
+    from imagescry_amd import EfficientNetEmbedder, efficientnet
+
+    sd = efficientnet.make_state_dict("s", seed=5, randomize_bn=True)
+    model = EfficientNetEmbedder(state_dict=sd).to(device)
+    x = torch.randn(shape, generator=cases.gen(shape[2])).clip(-3, 3)
+    with torch.no_grad():
+        exp = efficientnet_oracle.features(x, sd, _stages("s"))
+    got = model.forward(x.to(device)).cpu()
+    assert got.shape == exp.shape == (shape[0], 1280, math.ceil(shape[2] / 32), math.ceil(shape[3] / 32))
+    err = float((got - exp).abs().max() / exp.abs().max())
+    assert err < 5e-5, err
+
+
+def test_efficientnet_predict_step_matches_oracle(device: torch.device) -> None:
+    from imagescry_amd import EfficientNetEmbedder, ImageBatch, efficientnet
+
+    sd = efficientnet.make_state_dict("s", seed=6, randomize_bn=True)
+    model = EfficientNetEmbedder(state_dict=sd, max_side_length=64).to(device)
+    images = cases.images_u8((2, 3, 90, 70), seed=3)  # long side 90 > 64: resize branch
+    out = model.predict_step(ImageBatch(indices=torch.tensor([1, 0]), images=images).to(device))
+    with torch.no_grad():
+        x = encoder_oracle.preprocess(images, 64)
+        exp = encoder_oracle.l2_normalize_channels(efficientnet_oracle.features(x, sd, _stages("s")))
+    got = out.embeddings.cpu()
+    assert got.shape == exp.shape == (2, 1280, 2, 2)
+    np.testing.assert_allclose(got.numpy(), exp.numpy(), rtol=0, atol=1e-5)
+    flat = out.get_flat_vectors()
+    assert flat.shape == (8, 1280) and torch.allclose(flat.norm(dim=1).cpu(), torch.ones(8), atol=1e-5)
+    assert torch.equal(flat.cpu(), got.permute(0, 2, 3, 1).reshape(-1, 1280))
+
+
+@pytest.mark.parametrize("height", [35, 64, 128])
+@pytest.mark.parametrize("width", [42, 73, 96])
+@pytest.mark.parametrize("batch_size", [1, 2, 3])
+def test_embedding_predict_step(batch_size: int, height: int, width: int, device: torch.device) -> None:
+    """The reference's test, verbatim in structure (tests/test_models/test_embedding.py:78-106)."""
+    from imagescry_amd import ImageBatch
+
+    model = _model(device)
+    image_batch = ImageBatch(
+        indices=torch.arange(batch_size),
+        images=torch.randint(0, 256, (batch_size, 3, height, width)).to(torch.uint8),
+    ).to(model.device)
+    embedding_batch = model.predict_step(image_batch)
+    downsample_factor = 32
+    assert embedding_batch.embeddings.shape == (
+        batch_size, model.embedding_dim, math.ceil(height / downsample_factor), math.ceil(width / downsample_factor),
+    )
+
+
+_MODEL = None
+
+
+def _model(device: torch.device):
+    global _MODEL
+    if _MODEL is None:
+        from imagescry_amd import EfficientNetEmbedder
+
+        _MODEL = EfficientNetEmbedder().to(device)
+    return _MODEL
+
+
+def test_constructor_contract(device: torch.device) -> None:
+    from imagescry_amd import EfficientNetEmbedder
+
+    assert _model(device).embedding_dim == 1280 and _model(device).hparams == {"backbone_size": "s", "max_side_length": 640}
+    with pytest.raises(ValueError):
+        EfficientNetEmbedder(backbone_size="xl")
+    with pytest.raises(RuntimeError):
+        EfficientNetEmbedder(pretrained=True)

@@ -123,3 +123,21 @@ def test_bn_folding_and_krsc_layout_match_the_unfused_oracle() -> None:
     assert torch.allclose(got, exp, rtol=1e-4, atol=1e-5)
     assert float(net.stem.weight[:, 49:].abs().max()) == 0.0 and float(net.stem.weight[:, :, 3].abs().max()) == 0.0
     assert len(net.blocks) == 16 and sum(b.downsample is not None for b in net.blocks) == 4
+
+
+def test_efficientnet_v2_parameter_counts_match_torchvision() -> None:
+    """torchvision is absent, so the restated architecture is pinned by the published parameter totals of
+    efficientnet_v2_{s,m,l} (21,458,488 / 54,139,356 / 118,515,272) minus the 1280 -> 1000 classifier the reference
+    drops (`.features` only, embedding.py:147)."""
+    from imagescry_amd import efficientnet
+
+    for size, total in (("s", 21_458_488), ("m", 54_139_356), ("l", 118_515_272)):
+        sd = efficientnet.make_state_dict(size)
+        n = sum(v.numel() for k, v in sd.items() if "running" not in k)
+        assert n == total - (1280 * 1000 + 1000)
+    sd = efficientnet.make_state_dict("s")
+    assert sd["features.0.0.weight"].shape == (24, 3, 3, 3)
+    assert sd["features.2.0.block.0.0.weight"].shape == (96, 24, 3, 3)
+    assert sd["features.4.0.block.1.0.weight"].shape == (256, 1, 3, 3)  # depthwise
+    assert sd["features.4.0.block.2.fc1.weight"].shape == (16, 256, 1, 1)  # squeeze = in_channels // 4
+    assert sd["features.7.0.weight"].shape == (1280, 256, 1, 1)
