@@ -34,6 +34,8 @@
 //              matrix cores idle most of the time.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "bank_layout.h"
 #include "isc_common.h"
 
@@ -258,7 +260,8 @@ constexpr int A_TILE_BYTES = TM * 128;  // 32 KiB: one K step of one bank tile
 // read one iteration after the vmcnt + barrier that retires its DMA, and refilled one barrier after its last read.
 //
 // DBG is a bring-up aid (ISC_DEBUG_MODE environment variable, never set in production): 2 = no staging after the
-// prologue, 3 = staging but no MFMAs, 7 = like 2 without LDS fragment reads.  The filter never fires then.  Results are wrong for DBG != 0.
+// prologue, 3 = staging but no MFMAs, 7 = like 2 without LDS fragment reads (the filter never fires in these), 11 = production kernel without the
+// half-row-block stagger of the wm = 1 waves (A/B aid, correct results).  Results are wrong for DBG != 0.
 template <typename T, int TNQ, int DBG>
 __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* __restrict__ bank, int64_t r0,
                                                           int64_t r1, int tiles_per_chunk, int ntiles,
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases stay in SGPRs
     const int wm = wave / WN;  // which TM / WM bank rows of the tile
     const int wn = wave % WN;  // which 64 queries of the tile
     const int chunk = blockIdx.x;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         thr[n] = tau[q0 + wn * 64 + n * 16 + frow];
-        if (DBG != 0) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
+        if (DBG != 0 && DBG != 11) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
         cnt[n] = 0;
     }
 
@@ -381,6 +384,10 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     retire_for(0);
     __builtin_amdgcn_s_barrier();
 
+    // The main loop exists in two instantiations (see "type B" below); the branch is taken once, outside the loop,
+    // so neither version pays for the other's registers.
+    auto main_loop = [&](auto stagger_tag) {
+    constexpr bool STAGGER = decltype(stagger_tag)::value;
     int kt = 0, tile = 0;
     for (int step = 0; step < total_steps; ++step) {
         if constexpr (TNQ == 256 && DBG != 7) {
@@ -422,7 +429,46 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 #define ISC_MFMA_HALF(a_, b_, m_)                                                                         \
     if constexpr (DBG != 3) Mma<T>::half(a_, b_, acc[m_]);                                                 \
     else acc[m_][0][0] += __uint_as_float((a_)[0] ^ (b_)[1][1] ^ (b_)[2][2]);
-            // row block 0: its two halves arrive separately
+            // The two waves that share a SIMD (waves w and w + 4, i.e. wm = 0 and wm = 1) run the same program between
+            // the same barriers; left alone they reach their read / wait / DMA-issue instructions together and the
+            // matrix pipe idles meanwhile.  The wm = 1 waves therefore run a version shifted by half a row block:
+            // their overhead instructions sit between the two halves of a row block, the wm = 0 waves' between row
+            // blocks, so one partner is always issuing MFMAs.
+            if constexpr (STAGGER) {
+                // ---- type B: [first half of block m] [reads m + 2, DMA, wait for block m + 1] [second half of block m]
+                asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(ar[0][0]));
+                __builtin_amdgcn_sched_barrier(0);
+                ISC_MFMA_HALF(ar[0][0], b0, 0)
+                ISC_DS_READ(ar[2][0], a_addr0, 4096);  // R3
+                ISC_DS_READ(ar[2][1], a_addr1, 4096);
+                ISC_DMA(0)
+                asm volatile("s_waitcnt lgkmcnt(2)"
+                             : "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]), "+v"(ar[0][1]), "+v"(ar[1][0]),
+                               "+v"(ar[1][1]));
+                __builtin_amdgcn_sched_barrier(0);
+                ISC_MFMA_HALF(ar[0][1], b1, 0)
+#define ISC_ROW_BLOCK_B(m_, cur_, nxt_, nn_, wait_)                                                        \
+    ISC_MFMA_HALF(ar[cur_][0], b0, m_)                                                                     \
+    if constexpr ((m_) + 2 < 8) {                                                                          \
+        ISC_DS_READ(ar[nn_][0], a_addr0, ((m_) + 2) * 2048);                                               \
+        ISC_DS_READ(ar[nn_][1], a_addr1, ((m_) + 2) * 2048);                                               \
+    }                                                                                                      \
+    ISC_DMA(m_)                                                                                            \
+    if constexpr ((m_) + 1 < 8) {                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(" wait_ ")" : "+v"(ar[nxt_][0]), "+v"(ar[nxt_][1]), "+v"(ar[cur_][1])); \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }                                                                                                      \
+    ISC_MFMA_HALF(ar[cur_][1], b1, m_)
+                ISC_ROW_BLOCK_B(1, 1, 2, 0, "2")
+                ISC_ROW_BLOCK_B(2, 2, 0, 1, "2")
+                ISC_ROW_BLOCK_B(3, 0, 1, 2, "2")
+                ISC_ROW_BLOCK_B(4, 1, 2, 0, "2")
+                ISC_ROW_BLOCK_B(5, 2, 0, 1, "2")
+                ISC_ROW_BLOCK_B(6, 0, 1, 2, "0")
+                ISC_ROW_BLOCK_B(7, 1, 2, 0, "0")
+#undef ISC_ROW_BLOCK_B
+            } else {
+            // ---- type A.  row block 0: its two halves arrive separately
             ISC_DS_READ(ar[2][0], a_addr0, 4096);  // R3
             ISC_DS_READ(ar[2][1], a_addr1, 4096);
             asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(ar[0][0]));
@@ -449,6 +495,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             ISC_ROW_BLOCK(5, 2, 1, "4")
             ISC_ROW_BLOCK(6, 0, 2, "2")
             ISC_ROW_BLOCK(7, 1, 0, "0")
+            }
 #undef ISC_ROW_BLOCK
 #undef ISC_MFMA_HALF
 #undef ISC_DMA
@@ -564,6 +611,9 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
         retire_for(step + 1);
         __builtin_amdgcn_s_barrier();
     }
+    };
+    if (TNQ == 256 && DBG != 11 && __builtin_amdgcn_readfirstlane(wm) == 1) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
 
     // ---- tail: compact this lane's private survivors into the per-query list.  One returning atomic per
     // (lane, query block) with survivors, outside the hot loop; the order inside a list is arbitrary, the
@@ -825,6 +875,7 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
         case 2: ISC_LAUNCH_FILTER(2); break;
         case 3: ISC_LAUNCH_FILTER(3); break;
         case 7: ISC_LAUNCH_FILTER(7); break;
+        case 11: ISC_LAUNCH_FILTER(11); break;
         default: ISC_LAUNCH_FILTER(0); break;
     }
 #undef ISC_LAUNCH_FILTER
