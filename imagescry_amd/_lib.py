@@ -97,7 +97,9 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
         [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p,
          c_void_p, c_size_t, c_void_p],
     ),
-    "isc_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "isc_topk_merge": (
+        c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]
+    ),
 }
 
 _lib: ctypes.CDLL | None = None

@@ -16,16 +16,17 @@ __device__ __forceinline__ bool merge_better(float sa, int64_t ia, float sb, int
 // identical pair are broken by position so every rank is still unique.
 __global__ __launch_bounds__(256) void k_topk_merge(const float* __restrict__ scores,
                                                     const int64_t* __restrict__ indices, int G, int Q, int kin,
-                                                    int kout, float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+                                                    int kout, int64_t gs_scores, int64_t gs_indices,
+                                                    float* __restrict__ out_s, int64_t* __restrict__ out_i) {
     __shared__ float s[MERGE_CAP];
     __shared__ int64_t ix[MERGE_CAP];
     const int q = blockIdx.x;
     const int n = G * kin;
     for (int e = threadIdx.x; e < n; e += 256) {
         const int g = e / kin, j = e - g * kin;
-        const size_t src = ((size_t)g * Q + q) * kin + j;
-        s[e] = scores[src];
-        ix[e] = indices[src];
+        const size_t inner = (size_t)q * kin + j;
+        s[e] = scores[(size_t)g * gs_scores + inner];
+        ix[e] = indices[(size_t)g * gs_indices + inner];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < n; e += 256) {
@@ -147,13 +148,18 @@ int ex_check(int dtype, int64_t n, int d, int q, int k) {
 }  // namespace
 
 extern "C" int isc_topk_merge(const float* scores, const int64_t* indices, int G, int Q, int kin, int kout,
-                              float* out_scores, int64_t* out_indices, void* stream) {
+                              int64_t stride_g_scores, int64_t stride_g_indices, float* out_scores,
+                              int64_t* out_indices, void* stream) {
     ISC_REQUIRE(scores && indices && out_scores && out_indices);
     ISC_REQUIRE(G > 0 && Q > 0 && kin > 0 && kout > 0);
     if ((int64_t)G * kin > MERGE_CAP) return ISC_ERR_UNSUPPORTED;
     ISC_REQUIRE(kout <= G * kin);
+    const int64_t dense = (int64_t)Q * kin;
+    if (stride_g_scores == 0) stride_g_scores = dense;
+    if (stride_g_indices == 0) stride_g_indices = dense;
+    ISC_REQUIRE(stride_g_scores >= dense && stride_g_indices >= dense);
     hipLaunchKernelGGL(k_topk_merge, dim3(Q), dim3(256), 0, isc_stream(stream), scores, indices, G, Q, kin, kout,
-                       out_scores, out_indices);
+                       stride_g_scores, stride_g_indices, out_scores, out_indices);
     return isc_launch_status();
 }
 
@@ -187,7 +193,7 @@ extern "C" int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N
         hipLaunchKernelGGL(k_exhaustive<float>, dim3(p.chunks, Q), dim3(256), lds, s,
                            static_cast<const unsigned char*>(bank), isc_ksteps(D, 4), N, p.rows_per_chunk, static_cast<const float*>(queries), ldq, D, k, index_base, Q,
                            part_s, part_i);
-    hipLaunchKernelGGL(k_topk_merge, dim3(Q), dim3(256), 0, s, part_s, part_i, p.chunks * 4, Q, k, k, out_scores,
-                       out_indices);
+    hipLaunchKernelGGL(k_topk_merge, dim3(Q), dim3(256), 0, s, part_s, part_i, p.chunks * 4, Q, k, k, (int64_t)Q * k,
+                       (int64_t)Q * k, out_scores, out_indices);
     return isc_launch_status();
 }

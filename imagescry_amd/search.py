@@ -202,12 +202,18 @@ class EmbeddingBank:
             self._workspaces = {key: ws}  # keep one: the workspace can be > 100 MiB
         return ws
 
-    def _local_topk(self, queries: Tensor, k: int, check: bool) -> tuple[Tensor, Tensor]:
-        """Top-k of this rank's rows: `(float32 [Q, k], int64 [Q, k])` with GLOBAL row indices."""
+    def _local_topk(
+        self, queries: Tensor, k: int, check: bool, out: tuple[Tensor, Tensor, Tensor] | None = None
+    ) -> tuple[Tensor, Tensor]:
+        """Top-k of this rank's rows: `(float32 [Q, k], int64 [Q, k])` with GLOBAL row indices.  `out` optionally
+        supplies the (scores, indices, status int32[4]) tensors to write into (the exchange buffer of a sharded search)."""
         nq = queries.shape[0]
-        scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
-        indices = torch.empty((nq, k), dtype=torch.int64, device=self.device)
-        status = torch.empty(4, dtype=torch.int32, device=self.device)
+        if out is None:
+            scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+            indices = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+            status = torch.empty(4, dtype=torch.int32, device=self.device)
+        else:
+            scores, indices, status = out
         ws = self._workspace(nq, k)
         lib = _lib.load()
         code = _lib.dtype_code(self.dtype)
@@ -221,28 +227,36 @@ class EmbeddingBank:
             _lib.check(st, "isc_cosine_topk")
             self.last_status = status
             if check and int(status[0].item()) != 0:
-                # a candidate buffer overflowed (adversarially ordered or heavily duplicated bank):
-                # redo this call with the data-independent float64 kernel
-                need = _lib.c_size_t()
-                _lib.check(
-                    lib.isc_cosine_topk_exhaustive_workspace_bytes(code, self.num_local_rows, self.dim, nq, k, need),
-                    "isc_cosine_topk_exhaustive_workspace_bytes",
-                )
-                ews = torch.empty(need.value, dtype=torch.uint8, device=self.device)
-                st = lib.isc_cosine_topk_exhaustive(*args, ews.data_ptr(), ews.numel(), stream)
-                _lib.check(st, "isc_cosine_topk_exhaustive")
+                self._exhaustive(args, nq, k, stream)
         return scores, indices
 
+    def _exhaustive(self, args: tuple, nq: int, k: int, stream: int) -> None:
+        """A candidate buffer overflowed (adversarially ordered or heavily duplicated bank): redo the call with the
+        data-independent float64 kernel, into the same output tensors."""
+        lib = _lib.load()
+        code = _lib.dtype_code(self.dtype)
+        need = _lib.c_size_t()
+        _lib.check(
+            lib.isc_cosine_topk_exhaustive_workspace_bytes(code, self.num_local_rows, self.dim, nq, k, need),
+            "isc_cosine_topk_exhaustive_workspace_bytes",
+        )
+        ews = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        st = lib.isc_cosine_topk_exhaustive(*args, ews.data_ptr(), ews.numel(), stream)
+        _lib.check(st, "isc_cosine_topk_exhaustive")
+
     def _merge_topk(self, scores: Tensor, indices: Tensor, k: int) -> tuple[Tensor, Tensor]:
-        """Merge `[G, Q, kin]` partial results into `[Q, k]` by (score desc, index asc) (`isc_topk_merge`)."""
+        """Merge `[G, Q, kin]` partial results into `[Q, k]` by (score desc, index asc) (`isc_topk_merge`).  The two
+        inputs may be strided along G (views into the all-gathered exchange buffer); their `[Q, kin]` blocks are dense."""
         g, nq, kin = scores.shape
+        if scores.stride(1) != kin or scores.stride(2) != 1 or indices.stride(1) != kin or indices.stride(2) != 1:
+            scores, indices = scores.contiguous(), indices.contiguous()
         out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
         out_i = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
         lib = _lib.load()
         with torch.cuda.device(scores.device):
             st = lib.isc_topk_merge(
-                scores.contiguous().data_ptr(), indices.contiguous().data_ptr(), g, nq, kin, k, out_s.data_ptr(),
-                out_i.data_ptr(), _lib.stream_handle(scores.device),
+                scores.data_ptr(), indices.data_ptr(), g, nq, kin, k, scores.stride(0) if g > 1 else 0,
+                indices.stride(0) if g > 1 else 0, out_s.data_ptr(), out_i.data_ptr(), _lib.stream_handle(scores.device),
             )
         _lib.check(st, "isc_topk_merge")
         return out_s, out_i
@@ -282,31 +296,61 @@ class EmbeddingBank:
             self._n_total = self._total_rows()
         if k > self._n_total:
             raise ValueError(f"k={k} exceeds the bank size {self._n_total}")
-        kl = min(k, self.num_local_rows)
-        part_s = torch.full((nq, k), -math.inf, dtype=torch.float32, device=self.device)
-        part_i = torch.full((nq, k), _PAD_INDEX, dtype=torch.int64, device=self.device)
-        if kl > 0 and nq > 0:
-            s, i = self._local_topk(q, kl, check)
-            part_s[:, :kl] = s
-            part_i[:, :kl] = i
-        all_s, all_i = self._all_gather_partials(part_s, part_i)
         if nq == 0:
-            return part_s, part_i
-        return self._merge_topk(all_s, all_i, k)
+            return (torch.empty((0, k), dtype=torch.float32, device=self.device),
+                    torch.empty((0, k), dtype=torch.int64, device=self.device))
+        # exchange buffer of this rank: [scores f32 Q*k | indices i64 Q*k | status i32 x4], written in place by the
+        # search kernels, gathered with ONE collective and read in place by the merge kernel
+        off_i = (4 * nq * k + 7) // 8 * 8
+        off_s = off_i + 8 * nq * k
+        nbytes = off_s + 16
+        xbuf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        part_s = xbuf[: 4 * nq * k].view(torch.float32).view(nq, k)
+        part_i = xbuf[off_i:off_s].view(torch.int64).view(nq, k)
+        status = xbuf[off_s:].view(torch.int32)
+        kl = min(k, self.num_local_rows)
+        if kl < k:  # a shard with fewer rows than k: pad with entries that rank after every real candidate
+            part_s.fill_(-math.inf)
+            part_i.fill_(_PAD_INDEX)
+            status.zero_()
+            if kl > 0:
+                s, i = self._local_topk(q, kl, check)
+                part_s[:, :kl] = s
+                part_i[:, :kl] = i
+        else:
+            s, i = self._local_topk(q, k, False, out=(part_s, part_i, status))
+            if s.data_ptr() != part_s.data_ptr():  # a test double returned its own tensors
+                part_s.copy_(s)
+                part_i.copy_(i)
+                status.zero_()
+        for attempt in range(2):
+            gathered = self._all_gather_bytes(xbuf)
+            all_s = gathered[:, : 4 * nq * k].view(torch.float32).view(self.world_size, nq, k)
+            all_i = gathered[:, off_i:off_s].view(torch.int64).view(self.world_size, nq, k)
+            result = self._merge_topk(all_s, all_i, k)
+            if not check or attempt == 1 or kl < k:
+                return result
+            flags = gathered[:, off_s : off_s + 4].view(torch.int32).reshape(-1)
+            if not bool((flags != 0).any().item()):  # the one host synchronisation of a checked sharded search
+                return result
+            # some shard's candidate buffers overflowed: those ranks redo their shard exhaustively, then everybody
+            # exchanges and merges again (every rank sees the same flags, so the collective stays matched)
+            if int(status[0].item()) != 0:
+                qq = q
+                args = (
+                    self._bank.data_ptr(), _lib.dtype_code(self.dtype), self.num_local_rows, self.dim, qq.data_ptr(), nq,
+                    qq.stride(0), k, self.index_base, part_s.data_ptr(), part_i.data_ptr(),
+                )
+                with torch.cuda.device(self.device):
+                    self._exhaustive(args, nq, k, _lib.stream_handle(self.device))
+                status.zero_()
+        return result
 
-    def _all_gather_partials(self, part_s: Tensor, part_i: Tensor) -> tuple[Tensor, Tensor]:
-        """One collective for both arrays: the float32 scores travel bit-cast inside an int64 `[Q, k, 2]` buffer."""
-        nq, k = part_s.shape
-        packed = torch.empty((nq, k, 2), dtype=torch.int64, device=part_s.device)
-        packed[..., 0] = part_s.view(torch.int32).to(torch.int64)
-        packed[..., 1] = part_i
-        # rank-major concatenation along dim 0 (the form both RCCL and gloo accept), viewed as [G, Q, k, 2]
+    def _all_gather_bytes(self, xbuf: Tensor) -> Tensor:
+        """`[G, nbytes]` uint8: every rank's exchange buffer (one all-gather; RCCL over xGMI on the GPUs)."""
         # a gloo group exchanges host copies (used to rehearse the multi-rank path without RCCL)
-        on_host = dist.get_backend(self.process_group) == "gloo" and packed.device.type != "cpu"
-        src = packed.cpu() if on_host else packed
-        gathered = torch.empty((self.world_size * nq, k, 2), dtype=torch.int64, device=src.device)
+        on_host = dist.get_backend(self.process_group) == "gloo" and xbuf.device.type != "cpu"
+        src = xbuf.cpu() if on_host else xbuf
+        gathered = torch.empty(self.world_size * src.numel(), dtype=torch.uint8, device=src.device)
         dist.all_gather_into_tensor(gathered, src, group=self.process_group)
-        gathered = gathered.to(part_s.device).view(self.world_size, nq, k, 2)
-        all_s = gathered[..., 0].to(torch.int32).view(torch.float32)
-        all_i = gathered[..., 1].contiguous()
-        return all_s.contiguous(), all_i
+        return gathered.to(xbuf.device).view(self.world_size, src.numel())

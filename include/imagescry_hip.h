@@ -203,9 +203,11 @@ int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N, int D, co
                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* Merge G partial results (e.g. one per bank shard after the all-gather) into the final top-k by
- * (score descending, index ascending): scores float [G,Q,kin], indices int64 [G,Q,kin] -> [Q,kout], kout <= G*kin <= 4096. */
-int isc_topk_merge(const float* scores, const int64_t* indices, int G, int Q, int kin, int kout, float* out_scores,
-                   int64_t* out_indices, void* stream);
+ * (score descending, index ascending): scores float [G,Q,kin], indices int64 [G,Q,kin] -> [Q,kout], kout <= G*kin <= 4096.
+ * `stride_g_*` = distance in ELEMENTS between the [Q,kin] blocks of consecutive shards (0 = dense); this lets the merge
+ * read the all-gathered exchange buffers in place. */
+int isc_topk_merge(const float* scores, const int64_t* indices, int G, int Q, int kin, int kout, int64_t stride_g_scores,
+                   int64_t stride_g_indices, float* out_scores, int64_t* out_indices, void* stream);
 
 #ifdef __cplusplus
 }

@@ -63,7 +63,7 @@ def test_host_only_entry_points(library: ctypes.CDLL) -> None:
     assert lib.isc_channel_stats_workspace_bytes(_lib.ISC_U8, 512, 3, 224, 224, need) == 0
     assert need.value == 3 * 512 * 4 * 16  # 4 chunks of 16384 pixels per plane, 16 bytes per partial
     # NULL pointers are rejected before anything is launched
-    assert lib.isc_topk_merge(None, None, 1, 1, 1, 1, None, None, None) == _lib.ISC_ERR_INVALID_ARG
+    assert lib.isc_topk_merge(None, None, 1, 1, 1, 1, 0, 0, None, None, None) == _lib.ISC_ERR_INVALID_ARG
     assert lib.isc_l2norm_channels(None, 1, 1, 1, 1e-12, None, None) == _lib.ISC_ERR_INVALID_ARG
     with pytest.raises(ValueError):
         _lib.check(_lib.ISC_ERR_UNSUPPORTED, "x")

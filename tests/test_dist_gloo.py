@@ -42,7 +42,7 @@ def _worker(rank: int, world: int, port: int, n: int, k: int, out_dir: str) -> N
             def _store(self, embeddings, normalize):  # keep the rows on the CPU
                 return embeddings.contiguous()
 
-            def _local_topk(self, queries, kk, check):
+            def _local_topk(self, queries, kk, check, out=None):  # `out`: the product's exchange buffer (unused here)
                 s, i = search_oracle.cosine_topk(self._bank, queries, kk, index_base=self.index_base)
                 return torch.from_numpy(s), torch.from_numpy(i)
 
