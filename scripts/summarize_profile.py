@@ -26,6 +26,8 @@ def short(name: str) -> str | None:
         if k in name:
             if k == "k_conv_f32":
                 return "k_conv_f32<64,256>" if ("64, 256" in name or "Li64ELi256" in name) else "k_conv_f32<128,128>"
+            if k == "k_dots_filter":  # the two tile shapes are different kernels
+                return "k_dots_filter<256>" if ("Li256E" in name or ", 256," in name) else "k_dots_filter<64>"
             return k
     return None
 
@@ -55,18 +57,23 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_mfma"):
         for c, vals in counters.items():
             entry = summary["pmc_per_launch"].setdefault(k, {})
             entry[c] = {"launches": len(vals), "max": max(vals), "mean": sum(vals) / len(vals)}
-# derived numbers for the search kernel: the largest launch of a step is the level that streams the bank
-d = summary["pmc_per_launch"].get("k_dots_filter", {})
-if "FETCH_SIZE" in d:
+# derived numbers for the search kernels: the largest launch of a step is the level that streams the bank.
+# Calibration of FETCH_SIZE (MI355X_MICROARCH.md "HBM"): the 64-query-tile launch reads its 9.74 M bank rows exactly
+# once (14.96 GB) and reports 7.49e6 units of 1024 B, i.e. half the bytes -- the guide's factor 2 holds for this
+# kernel's 16 B / lane LDS-DMA stream and is applied below.
+for variant in ("k_dots_filter<256>", "k_dots_filter<64>"):
+    d = summary["pmc_per_launch"].get(variant, {})
+    if "FETCH_SIZE" not in d:
+        continue
     big = {
-        "hbm_read_bytes_corrected": d["FETCH_SIZE"]["max"] * 1024 * 2,
-        "hbm_write_bytes": d.get("WRITE_SIZE", {}).get("max", 0) * 1024,
-        "hbm_read_bytes_all_launches_of_a_step_corrected": d["FETCH_SIZE"]["mean"] * 3 * 1024 * 2,
+        "hbm_read_bytes_corrected_max": d["FETCH_SIZE"]["max"] * 1024 * 2,
+        "hbm_read_bytes_corrected_mean_per_launch": d["FETCH_SIZE"]["mean"] * 1024 * 2,
+        "hbm_write_bytes_max": d.get("WRITE_SIZE", {}).get("max", 0) * 1024,
     }
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
         busy = d["SQ_VALU_MFMA_BUSY_CYCLES"]["max"] / 1024.0  # per SIMD (256 CUs x 4)
         active = d["GRBM_GUI_ACTIVE"]["max"] / 8.0  # per XCD
-        big["mfma_busy_frac"] = round(busy / active, 4)
-    summary["k_dots_filter_largest_launch"] = big
+        big["mfma_busy_frac_largest_launch"] = round(busy / active, 4)
+    summary[variant + "_derived"] = big
 out.write_text(json.dumps(summary, indent=1))
-print(json.dumps(summary, indent=1))
+print(json.dumps({k: v for k, v in summary.items() if k.endswith("_derived") or k == "kernel_stats"}, indent=1))
