@@ -5,7 +5,7 @@ Public surface (same names as the reference where the reference has them):
 * `ImageBatch`, `EmbeddingBatch`                 -- reference src/imagescry/data.py:29-144
 * `resize`, `normalize_per_channel`, `to_4d`     -- reference src/imagescry/image/transforms.py
 * `EmbeddingModule`, `EfficientNetEmbedder`,
-  `ResNet50Embedder`                             -- reference src/imagescry/models/embedding.py:27-183
+  `ResNet50Embedder`, `ViTB16Embedder`           -- reference src/imagescry/models/embedding.py:27-183
 * `PCA`, `EmbeddingPCAPipeline`                  -- reference src/imagescry/models/decomposition.py, pipelines.py
 * `EmbeddingBank`                                -- cosine top-k search (new; see search.py)
 
@@ -16,7 +16,13 @@ PyTorch is used for device memory, streams and `torch.distributed` only.
 from imagescry_amd.batching import ImageTensorDataset, SimilarShapeBatcher
 from imagescry_amd.data import EmbeddingBatch, ImageBatch
 from imagescry_amd.decomposition import PCA
-from imagescry_amd.embedding import EfficientNetEmbedder, EmbeddingModule, ResNet50Embedder, l2_normalize_channels
+from imagescry_amd.embedding import (
+    EfficientNetEmbedder,
+    EmbeddingModule,
+    ResNet50Embedder,
+    ViTB16Embedder,
+    l2_normalize_channels,
+)
 from imagescry_amd.pipelines import EmbeddingPCAPipeline
 from imagescry_amd.search import EmbeddingBank, shard_bounds
 from imagescry_amd.transforms import normalize_per_channel, resize, to_4d
@@ -29,6 +35,7 @@ __all__ = [
     "EmbeddingPCAPipeline",
     "PCA",
     "ResNet50Embedder",
+    "ViTB16Embedder",
     "l2_normalize_channels",
     "ImageBatch",
     "ImageTensorDataset",

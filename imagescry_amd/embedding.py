@@ -15,11 +15,11 @@ from typing import Iterable
 import torch
 from torch import Tensor
 
-from imagescry_amd import _lib, efficientnet, resnet50
+from imagescry_amd import _lib, efficientnet, resnet50, vit
 from imagescry_amd.data import EmbeddingBatch, ImageBatch
 from imagescry_amd.transforms import normalize_per_channel, resize
 
-__all__ = ["EfficientNetEmbedder", "EmbeddingModule", "ResNet50Embedder", "l2_normalize_channels"]
+__all__ = ["EfficientNetEmbedder", "EmbeddingModule", "ResNet50Embedder", "ViTB16Embedder", "l2_normalize_channels"]
 
 
 def l2_normalize_channels(x: Tensor, eps: float = 1e-12) -> Tensor:
@@ -316,3 +316,63 @@ class EfficientNetEmbedder(EmbeddingModule):
                 outs.append(efficientnet.forward_features(self._net, x[b0 : b0 + chunk]))
         y = outs[0] if len(outs) == 1 else torch.cat(outs)
         return y.permute(0, 3, 1, 2)
+
+
+class ViTB16Embedder(EmbeddingModule):
+    """ViT-B/16 -> 768-d class-token embedding, fp16 matrix-core arithmetic (BASELINE.json configs[4]).
+
+    Same constructor style as the other embedders.  A ViT has a fixed token grid, so `preprocess` resizes every batch
+    to `image_size` x `image_size` (the reference's `resize` with a tuple size, transforms.py:78-126) before the
+    batch-statistics normalisation; the output map is `[B, 768, 1, 1]`, one bank row per image.
+    """
+
+    def __init__(
+        self,
+        *,
+        config: vit.ViTConfig = vit.VIT_B16,
+        state_dict: dict[str, Tensor] | None = None,
+        seed: int = 0,
+        max_images_per_pass: int = 1024,
+    ) -> None:
+        super().__init__()
+        if max_images_per_pass <= 0:
+            raise ValueError(f"max_images_per_pass must be positive, got {max_images_per_pass}")
+        self.config = config
+        self.max_images_per_pass = max_images_per_pass
+        self.hparams = {"image_size": config.image_size, "patch_size": config.patch_size, "depth": config.depth}
+        sd = state_dict if state_dict is not None else vit.make_state_dict(config, seed=seed)
+        self._net = vit.prepare(sd, config)
+
+    def _move(self, device: torch.device) -> None:
+        self._net = self._net.to(device)
+
+    @property
+    def embedding_dim(self) -> int:
+        return self.config.dim
+
+    def preprocess(self, images: Tensor) -> Tensor:
+        if not isinstance(images, Tensor) or images.dtype != torch.uint8:
+            raise TypeError("images must be a uint8 tensor")
+        if images.ndim != 4:
+            raise ValueError(f"images must have shape [B, C, H, W], got {tuple(images.shape)}")
+        s = self.config.image_size
+        if tuple(images.shape[-2:]) != (s, s):
+            images = resize(images, output_size=(s, s))
+        return normalize_per_channel(images, min_value=-3, max_value=3)
+
+    def forward(self, x: Tensor) -> Tensor:
+        if not isinstance(x, Tensor) or x.dtype != torch.float32:
+            raise TypeError("x must be a float32 tensor")
+        s = self.config.image_size
+        if x.ndim != 4 or tuple(x.shape[1:]) != (3, s, s):
+            raise ValueError(f"x must have shape [B, 3, {s}, {s}], got {tuple(x.shape)}")
+        _lib.require_device(x, "x")
+        if self.device != x.device:
+            raise ValueError(f"module is on {self.device} but the input is on {x.device}; call .to() first")
+        x = x.contiguous()
+        b = x.shape[0]
+        out = torch.empty((b, self.config.dim), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            for b0 in range(0, b, self.max_images_per_pass):
+                out[b0 : b0 + self.max_images_per_pass] = vit.forward_cls(self._net, x[b0 : b0 + self.max_images_per_pass])
+        return out[:, :, None, None]

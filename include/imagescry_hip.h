@@ -63,7 +63,8 @@ int isc_device_info(int* num_cus, int* lds_bytes_per_cu, char* arch_name, int ar
  * returns the summed device time and the launch count since the last read, and clears them (host pointers). */
 #define ISC_KERNEL_DOTS_FILTER 0 /* k_dots_filter: the MFMA score + threshold-filter pass of isc_cosine_topk */
 #define ISC_KERNEL_CONV 1        /* k_conv_f32: the implicit-GEMM convolution of isc_conv2d_nhwc */
-#define ISC_KERNEL_COUNT 2
+#define ISC_KERNEL_GEMM_F16 2    /* k_gemm_f16: the fp16 GEMM of isc_gemm_f16 (transformer encoder) */
+#define ISC_KERNEL_COUNT 3
 int isc_timing_enable(int enable);
 int isc_timing_read(int kernel_id, double* total_ms, int* launches);
 
@@ -169,6 +170,35 @@ int isc_maxpool_nhwc(const float* x, int B, int H, int W, int C, int R, int stri
 
 /* global average pooling, NHWC float [B,H,W,C] -> [B,C]. */
 int isc_global_avgpool_nhwc(const float* x, int B, int H, int W, int C, float* y, void* stream);
+
+/* ---- transformer encoder blocks (ViT-B/16, BASELINE.json configs[4]); fp16 operands, float32 accumulation -------
+ * The reference's encoder is any `EmbeddingModule.forward` (models/embedding.py:91-104); these are the blocks a
+ * ViT forward is composed of (torch.nn.Linear / LayerNorm / scaled_dot_product_attention in a torch build). */
+
+/* out[M,N] = act(a[M,K] . w[N,K]^T + bias[N]) + residual[M,N].   a, w fp16 row-major (w in torch.nn.Linear layout);
+ * bias, residual float32 (either may be NULL); act ISC_ACT_NONE or ISC_ACT_GELU; out fp16 or float32 (`out_dtype`).
+ * K % 64 == 0, N % 4 == 0, all pointers 16-byte aligned. */
+int isc_gemm_f16(const void* a, int64_t M, int K, const void* w, int N, const float* bias, const float* residual,
+                 int act, void* out, int out_dtype, void* stream);
+
+/* LayerNorm over the last axis (biased variance, float32 statistics): x float32 [rows, D] with row stride ldx,
+ * y fp16 or float32 (`y_dtype`) with row stride ldy (strides in elements, multiples of 4).  D % 4 == 0, D <= 2048. */
+int isc_layernorm(const float* x, int64_t rows, int D, int64_t ldx, const float* gamma, const float* beta, float eps,
+                  void* y, int y_dtype, int64_t ldy, void* stream);
+
+/* softmax(q k^T / sqrt(head_dim)) v per (image, head).  qkv fp16 [B, T, 3 * heads * head_dim] laid out as the output
+ * of one fused Linear whose weight rows are [query; key; value], each head-major; out fp16 [B, T, heads * head_dim].
+ * head_dim == 64, T <= 224. */
+int isc_attention_f16(const void* qkv, int B, int T, int heads, int head_dim, void* out, void* stream);
+
+/* non-overlapping patches of an NCHW float32 image batch as fp16 GEMM rows:
+ * patches[(b, ph, pw)][c * P * P + r * P + s] = x[b][c][ph * P + r][pw * P + s]   (torch Conv2d(kernel=stride=P) weight
+ * order).  P % 8 == 0, H % P == 0, W % P == 0. */
+int isc_patchify_f16(const float* x, int B, int C, int H, int W, int patch, void* patches, void* stream);
+
+/* tokens[b][0] = cls + pos[0]; tokens[b][t] = patch_embed[b * (T - 1) + t - 1] + pos[t]; all float32, D % 4 == 0. */
+int isc_vit_assemble(const float* patch_embed, const float* cls_token, const float* pos_embed, int B, int T, int D,
+                     float* tokens, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Search
