@@ -11,7 +11,8 @@ generates rows [r*N/G, (r+1)*N/G) on its device, seed 1234 + r); a step is one `
 local MFMA filter + exact re-score, one RCCL all-gather of the Q x k partials, merge.  `value` = queries/s.
 
 Secondary (reported in the same JSON line under "encode", rank 0's GPU only): ResNet-50 -> 768-d float32
-`predict_step` on 512 random 224 x 224 uint8 images (BASELINE.json config 2), images/s.
+`predict_step` on 512 random 224 x 224 uint8 images (BASELINE.json config 2), images/s; and under "encode_vit_b16"
+the same batch through the ViT-B/16 fp16 embedder (config 5).
 
 `--workload encode` makes the encode the primary metric instead (replicas: every rank encodes its own batch of
 512, weak scaling, no collective).
@@ -34,7 +35,9 @@ import torch.distributed as dist
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-from imagescry_amd import EmbeddingBank, ImageBatch, ResNet50Embedder, _lib, resnet50, shard_bounds  # noqa: E402
+from imagescry_amd import (  # noqa: E402
+    EmbeddingBank, ImageBatch, ResNet50Embedder, ViTB16Embedder, _lib, resnet50, shard_bounds, vit,
+)
 
 SEED = 1234
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -117,6 +120,21 @@ def make_shard(lo: int, hi: int, dim: int, device: torch.device, seed: int) -> t
         blk = torch.randn((min(1 << 20, hi - lo - r0), dim), generator=g, device=device)
         out[r0 : r0 + blk.shape[0]] = torch.nn.functional.normalize(blk, dim=1).half()
     return out
+
+
+def measured_traffic(config: dict) -> tuple[float | None, str | None]:
+    """HBM bytes per `k_dots_filter` launch from the newest committed PMC summary whose workload equals `config`
+    (profiles/*_headline_traffic.json, written by scripts/summarize_headline_traffic.py from separate rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes; counters cannot be read from inside this process)."""
+    keys = ("bank_rows", "dim", "queries", "k", "rows_per_gpu")
+    for f in sorted((ROOT / "profiles").glob("*_headline_traffic.json"), reverse=True):
+        try:
+            t = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if all(t.get("config", {}).get(k) == config.get(k) for k in keys):
+            return float(t["hbm_bytes_per_launch"]), f"profiles/{f.name}"
+    return None, None
 
 
 def search_roofline(rows: int, d: int, q: int, k: int, kernel_ms_per_step: float, launches_per_step: float) -> dict:
@@ -203,6 +221,12 @@ def bench_search(args: argparse.Namespace, rank: int, world: int, device: torch.
     sweep = None
     if world == 1 and not args.no_sweep:
         sweep = query_sweep(bank, rows, d, k, device)
+    traffic, traffic_src = measured_traffic({"bank_rows": n, "dim": d, "queries": q, "k": k, "rows_per_gpu": rows})
+    roofline["traffic"] = traffic
+    if traffic_src:
+        roofline["traffic_source"] = traffic_src
+        roofline["traffic_over_algorithmic"] = round(
+            traffic / (roofline["algorithmic_bytes_per_step"] / max(roofline["launches_per_step"], 1e-9)), 3)
     return {
         "metric": "queries/s cosine top-10 over N x D bank",
         "value": round(q * args.steps / seconds, 1),
@@ -299,6 +323,49 @@ def bench_encode(args: argparse.Namespace, rank: int, world: int, device: torch.
     }
 
 
+def bench_encode_vit(args: argparse.Namespace, device: torch.device, steps: int, warmup: int) -> dict:
+    """BASELINE.json configs[4]: ViT-B/16 (random weights) -> 768-d, fp16 matrix-core arithmetic, batch 512."""
+    b = args.batch
+    model = ViTB16Embedder(seed=0).to(device)
+    images = torch.randint(0, 256, (b, 3, 224, 224), dtype=torch.uint8,
+                           generator=torch.Generator().manual_seed(SEED)).to(device)
+    batch = ImageBatch(indices=torch.arange(b, device=device), images=images)
+    for _ in range(warmup):
+        model.predict_step(batch)
+    _lib.timing_enable(True)
+    _lib.timing_read(_lib.ISC_KERNEL_GEMM_F16)
+    seconds = timed_steps(lambda: model.predict_step(batch), steps, 0, 1, device)
+    kernel_ms, launches = _lib.timing_read(_lib.ISC_KERNEL_GEMM_F16)
+    _lib.timing_enable(False)
+    cfg = vit.VIT_B16
+    t, d = cfg.tokens, cfg.dim
+    gemm_flops = float(b) * (2 * (t - 1) * d * 3 * cfg.patch_size**2
+                             + cfg.depth * (2 * t * d * 3 * d + 2 * t * d * d + 4 * t * d * cfg.mlp_dim))
+    tflops = gemm_flops * steps / (kernel_ms / 1e3) / 1e12
+    return {
+        "metric": "images/s encode",
+        "value": round(b * steps / seconds, 1),
+        "unit": "images/s",
+        "ms_per_step": round(seconds / steps * 1e3, 3),
+        "dtype": "f16",
+        "config": {"workload": f"ViT-B/16 (random weights) batch-{b} 224x224 uint8 -> 768-d predict_step, fp16 operands / "
+                               f"float32 accumulation (BASELINE config 5)", "batch_per_gpu": b, "parallelism": "replicas1"},
+        "roofline": {
+            "kernel": "k_gemm_f16",
+            "bound": "mfma",
+            "achieved": round(tflops, 2),
+            "peak": MFMA_F16_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(tflops / MFMA_F16_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "launches_per_step": launches / steps,
+            "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
+            "kernel_ms_per_step": round(kernel_ms / steps, 3),
+            "algorithmic_flops_per_step": gemm_flops,
+        },
+    }
+
+
 def cpu_baseline_encode(args: argparse.Namespace) -> dict:
     from oracle import encoder_oracle
 
@@ -334,12 +401,15 @@ def main() -> None:
         primary = bench_search(args, rank, world, device)
         primary.pop("_bank"), primary.pop("_queries")
         torch.cuda.empty_cache()
-        secondary = None
+        secondary = secondary_vit = None
         if not args.no_secondary and rank == 0:
             secondary = bench_encode(args, rank, world, device, steps=3, warmup=1, collective_timing=False)
+            secondary.pop("_model"), secondary.pop("_images")
+            torch.cuda.empty_cache()
+            secondary_vit = bench_encode_vit(args, device, steps=3, warmup=1)
     else:
         primary = bench_encode(args, rank, world, device, args.steps, args.warmup, collective_timing=True)
-        secondary = None
+        secondary = secondary_vit = None
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -370,6 +440,8 @@ def main() -> None:
             if world == 1 and not args.no_cpu_baseline:
                 enc["cpu_baseline"] = cpu_baseline_encode(args)
             line["encode"] = enc
+        if secondary_vit is not None:
+            line["encode_vit_b16"] = secondary_vit
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16(const GemmParams p) {
 // ---------------------------------------------------------------------------------------------------------
 // LayerNorm over the last axis, one wave per row: y = (x - mean) / sqrt(var + eps) * gamma + beta, biased variance,
 // float32 statistics (two passes over registers).  D % 4 == 0, D <= 2048.
-template <bool OUT_F32>
+template <bool OUT_F32, int NV>
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, long long rows, int D, long long ldx,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    float eps, void* __restrict__ y, long long ldy) {
@@ -164,10 +164,10 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     const int lane = threadIdx.x & 63;
     const float* xr = x + (size_t)row * ldx;
     const int nvec = D >> 2;
-    f32x4 v[8];
+    f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < nvec) v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     const float mean = isc_wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < nvec) {
 #pragma unroll
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     }
     const float rstd = 1.f / sqrtf(isc_wave_sum(q) / (float)D + eps);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c >= nvec) continue;
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
@@ -203,6 +203,18 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
             *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(y) + (size_t)row * ldy + 4 * c) = h;
         }
     }
+}
+
+template <bool OUT_F32>
+void launch_layernorm(int nv, dim3 grid, hipStream_t s, const float* x, long long rows, int D, long long ldx,
+                      const float* gamma, const float* beta, float eps, void* y, long long ldy) {
+    // NV = 16-byte vectors per lane: the smallest instantiation that covers D keeps the register count (and so the
+    // number of rows in flight per CU) where this bandwidth-bound kernel needs it
+    if (nv <= 1) hipLaunchKernelGGL((k_layernorm<OUT_F32, 1>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy);
+    else if (nv <= 2) hipLaunchKernelGGL((k_layernorm<OUT_F32, 2>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy);
+    else if (nv <= 3) hipLaunchKernelGGL((k_layernorm<OUT_F32, 3>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy);
+    else if (nv <= 4) hipLaunchKernelGGL((k_layernorm<OUT_F32, 4>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy);
+    else hipLaunchKernelGGL((k_layernorm<OUT_F32, 8>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -423,12 +435,13 @@ extern "C" int isc_layernorm(const float* x, int64_t rows, int D, int64_t ldx, c
     const long long blocks = isc_ceil_div<long long>(rows, 4);
     if (blocks > 0x7fffffffLL) return ISC_ERR_UNSUPPORTED;
     hipStream_t s = isc_stream(stream);
+    const int nv = (D / 4 + 63) / 64;
     if (y_dtype == ISC_F32)
-        hipLaunchKernelGGL((k_layernorm<true>), dim3((unsigned)blocks), dim3(256), 0, s, x, (long long)rows, D,
-                           (long long)ldx, gamma, beta, eps, y, (long long)ldy);
+        launch_layernorm<true>(nv, dim3((unsigned)blocks), s, x, (long long)rows, D, (long long)ldx, gamma, beta, eps, y,
+                               (long long)ldy);
     else
-        hipLaunchKernelGGL((k_layernorm<false>), dim3((unsigned)blocks), dim3(256), 0, s, x, (long long)rows, D,
-                           (long long)ldx, gamma, beta, eps, y, (long long)ldy);
+        launch_layernorm<false>(nv, dim3((unsigned)blocks), s, x, (long long)rows, D, (long long)ldx, gamma, beta, eps, y,
+                                (long long)ldy);
     return isc_launch_status();
 }
 

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""gpurun_out/pmc_headline_<tag>/ (scripts/pmc_headline.sh) -> profiles/<tag>_headline_traffic.json.
+
+HBM bytes per `k_dots_filter` launch of the headline step, as MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE and
+WRITE_SIZE come from separate passes and are in units of 1024 B; on gfx950 FETCH_SIZE reports half of the bytes of
+this kernel's 16 B / lane stream (calibrated in profiles/r01_summary.json: the single-pass 64-query launch reads its
+bank rows exactly once), so the read side is doubled; WRITE_SIZE is exact.  bench.py copies `hbm_bytes_per_launch`
+into `roofline.traffic` when the workload matches.
+"""
+from __future__ import annotations
+
+import csv
+import glob
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+tag = sys.argv[1]
+src = ROOT / "gpurun_out" / f"pmc_headline_{tag}"
+
+
+def total(sub: str, counter: str) -> tuple[float, int]:
+    files = glob.glob(str(src / sub / "*/*counter_collection.csv"))
+    s, n = 0.0, 0
+    for r in csv.DictReader(open(files[0])):
+        if "k_dots_filter" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            s += float(r["Counter_Value"])
+            n += 1
+    return s, n
+
+
+bench = json.loads((src / "bench_fetch.json").read_text().strip().splitlines()[-1])
+fetch, n_f = total("fetch", "FETCH_SIZE")
+write, n_w = total("write", "WRITE_SIZE")
+assert n_f == n_w and n_f > 0
+read_b = fetch * 1024 * 2 / n_f
+write_b = write * 1024 / n_w
+algo = bench["roofline"]["algorithmic_bytes_per_step"] / bench["roofline"]["launches_per_step"]
+out = {
+    "tag": tag,
+    "config": bench["config"],
+    "kernel": "k_dots_filter",
+    "launches_profiled": n_f,
+    "hbm_read_bytes_per_launch": read_b,
+    "hbm_write_bytes_per_launch": write_b,
+    "hbm_bytes_per_launch": read_b + write_b,
+    "algorithmic_bytes_per_launch": algo,
+    "ratio_to_algorithmic": (read_b + write_b) / algo,
+    "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), x1024 B, FETCH_SIZE x2 (gfx950)",
+}
+(ROOT / "profiles" / f"{tag}_headline_traffic.json").write_text(json.dumps(out, indent=1))
+print(json.dumps(out, indent=1))
