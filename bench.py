@@ -50,12 +50,14 @@ def parse_args() -> argparse.Namespace:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["search", "encode"], default="search")
+    ap.add_argument("--workload", choices=["search", "encode", "pipeline"], default="search")
     ap.add_argument("--bank-rows", type=int, default=10_000_000, help="total bank rows (all ranks together)")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--batch", type=int, default=512, help="encode batch (images per step per rank)")
+    ap.add_argument("--pipeline-rows", type=int, default=50_000_000, help="bank rows of --workload pipeline (all ranks)")
+    ap.add_argument("--no-overlap", action="store_true", help="--workload pipeline: one stream instead of two")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the query-count sweep {1,16,64,256,1024} (N = 1 only)")
@@ -366,6 +368,47 @@ def bench_encode_vit(args: argparse.Namespace, device: torch.device, steps: int,
     }
 
 
+def bench_pipeline(args: argparse.Namespace, rank: int, world: int, device: torch.device) -> dict:
+    """BASELINE.json configs[4]: ViT-B/16 fp16 encode of 512-image batches pipelined into a row-sharded
+    50 M x 768 fp16 search, encode and search on two HIP streams.  A step = every rank encodes one batch of 512 and all
+    world * 512 embeddings are searched (top-10) against the whole bank.  value = images/s = queries/s, whole job."""
+    from imagescry_amd import EmbedSearchPipeline
+
+    n, d, b, k = args.pipeline_rows, args.dim, args.batch, args.k
+    lo, hi = shard_bounds(n, world, rank)
+    shard = make_shard(lo, hi, d, device, SEED + rank)
+    group = dist.group.WORLD if world > 1 else None
+    bank = EmbeddingBank(shard, dtype=torch.float16, normalize=False, index_base=lo, process_group=group, presharded=True)
+    del shard
+    torch.cuda.empty_cache()
+    model = ViTB16Embedder(seed=0).to(device)
+    images = torch.randint(0, 256, (b, 3, 224, 224), dtype=torch.uint8,
+                           generator=torch.Generator().manual_seed(SEED + rank)).to(device)
+    batch = ImageBatch(indices=torch.arange(b, device=device), images=images)
+    pipe = EmbedSearchPipeline(embedding_model=model, bank=bank, k=k, overlap=not args.no_overlap)
+    pipe.run([batch] * max(args.warmup, 1))
+    fence(world)
+    t0 = time.perf_counter()
+    results = pipe.run([batch] * args.steps)  # one call: batches stream through the two HIP streams back to back
+    fence(world)
+    seconds = max_over_ranks(time.perf_counter() - t0, world, device)
+    assert len(results) == args.steps and results[-1].neighbours.shape == (b, k)
+    return {
+        "metric": "images/s encoded and searched (ViT-B/16 fp16 -> cosine top-10)",
+        "value": round(b * world * args.steps / seconds, 1),
+        "unit": "images/s",
+        "ms_per_step": round(seconds / args.steps * 1e3, 3),
+        "scaling": "weak",
+        "dtype": "f16",
+        "config": {"workload": f"ViT-B/16 fp16 encode of {b}-image batches per rank pipelined into cosine top-{k} over a "
+                               f"{n} x {d} fp16 bank row-sharded {world} way(s); "
+                               f"{'two HIP streams' if not args.no_overlap else 'one stream'} (BASELINE config 5)",
+                   "bank_rows": n, "dim": d, "batch_per_gpu": b, "k": k, "rows_per_gpu": hi - lo,
+                   "parallelism": f"encode replicas{world} + row-shard{world}" + ("+allgather" if world > 1 else "")},
+        "roofline": None,
+    }
+
+
 def cpu_baseline_encode(args: argparse.Namespace) -> dict:
     from oracle import encoder_oracle
 
@@ -407,6 +450,9 @@ def main() -> None:
             secondary.pop("_model"), secondary.pop("_images")
             torch.cuda.empty_cache()
             secondary_vit = bench_encode_vit(args, device, steps=3, warmup=1)
+    elif args.workload == "pipeline":
+        primary = bench_pipeline(args, rank, world, device)
+        secondary = secondary_vit = None
     else:
         primary = bench_encode(args, rank, world, device, args.steps, args.warmup, collective_timing=True)
         secondary = secondary_vit = None
@@ -434,7 +480,9 @@ def main() -> None:
         if primary.get("q_sweep"):
             line["q_sweep"] = primary["q_sweep"]
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_search(args) if args.workload == "search" else cpu_baseline_encode(args)
+            if args.workload != "pipeline":
+                line["cpu_baseline"] = (cpu_baseline_search(args) if args.workload == "search"
+                                        else cpu_baseline_encode(args))
         if secondary is not None:
             enc = strip(secondary)
             if world == 1 and not args.no_cpu_baseline:

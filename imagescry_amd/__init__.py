@@ -7,6 +7,7 @@ Public surface (same names as the reference where the reference has them):
 * `EmbeddingModule`, `EfficientNetEmbedder`,
   `ResNet50Embedder`, `ViTB16Embedder`           -- reference src/imagescry/models/embedding.py:27-183
 * `PCA`, `EmbeddingPCAPipeline`                  -- reference src/imagescry/models/decomposition.py, pipelines.py
+* `EmbedSearchPipeline`                          -- encode -> search on two HIP streams (BASELINE config 5; new)
 * `EmbeddingBank`                                -- cosine top-k search (new; see search.py)
 
 All arithmetic runs in hand-written HIP kernels behind the C ABI of include/imagescry_hip.h;
@@ -23,7 +24,7 @@ from imagescry_amd.embedding import (
     ViTB16Embedder,
     l2_normalize_channels,
 )
-from imagescry_amd.pipelines import EmbeddingPCAPipeline
+from imagescry_amd.pipelines import EmbeddingPCAPipeline, EmbedSearchPipeline, SearchResult
 from imagescry_amd.search import EmbeddingBank, shard_bounds
 from imagescry_amd.transforms import normalize_per_channel, resize, to_4d
 
@@ -33,6 +34,8 @@ __all__ = [
     "EmbeddingBatch",
     "EmbeddingModule",
     "EmbeddingPCAPipeline",
+    "EmbedSearchPipeline",
+    "SearchResult",
     "PCA",
     "ResNet50Embedder",
     "ViTB16Embedder",

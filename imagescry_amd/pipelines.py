@@ -1,4 +1,4 @@
-"""Embed-then-compress pipeline (the caller of the hot path).
+"""Callers of the hot path: embed-then-compress (the reference's pipeline) and embed-then-search (BASELINE config 5).
 
 Mirrors the arithmetic of the reference's `EmbeddingPCAPipeline.predict_step` / `predict`
 (src/imagescry/models/pipelines.py:22-131): embedder.predict_step -> flat vectors -> PCA.transform -> back to
@@ -8,17 +8,21 @@ table (`imagescry_amd.storage.write_embeddings`, the format of storage/models.py
 
 from __future__ import annotations
 
+from dataclasses import dataclass
 from os import PathLike
 from typing import Iterable, Sequence
 
 import torch
+import torch.distributed as dist
+from torch import Tensor
 
 from imagescry_amd import storage
 from imagescry_amd.data import EmbeddingBatch, ImageBatch
 from imagescry_amd.decomposition import PCA
 from imagescry_amd.embedding import EmbeddingModule
+from imagescry_amd.search import EmbeddingBank
 
-__all__ = ["EmbeddingPCAPipeline"]
+__all__ = ["EmbedSearchPipeline", "EmbeddingPCAPipeline", "SearchResult"]
 
 
 class EmbeddingPCAPipeline:
@@ -67,3 +71,114 @@ class EmbeddingPCAPipeline:
         if self.db is None:
             return results  # type: ignore[return-value]
         return [row_id for ids in results for row_id in ids]  # type: ignore[union-attr]
+
+
+@dataclass(frozen=True)
+class SearchResult:
+    """Top-k neighbours of the images of one batch: `indices` are the batch's own `ImageBatch.indices`,
+    `scores` float32 `[R, k]` / `neighbours` int64 `[R, k]` one row per embedding vector (R = B for a `[B, E, 1, 1]`
+    embedder, B * h * w for a spatial one, in `get_flat_vectors()` order)."""
+
+    indices: Tensor
+    scores: Tensor
+    neighbours: Tensor
+
+
+class EmbedSearchPipeline:
+    """Encode image batches and search their embeddings in a bank, the encode of batch i + 1 overlapped with the
+    search of batch i on two HIP streams (BASELINE.json configs[4]: "ViT-B/16 fp16 encode pipelined into 50M x 768
+    sharded search, encode/search overlapped on HIP streams").
+
+    The reference has neither step combined (its caller of the embedder is `EmbeddingPCAPipeline`, pipelines.py:22-131);
+    the loop below is that class's `predict` with the search in place of the PCA.
+
+    One process per GPU.  With a row-sharded bank (`bank.process_group` set) every rank encodes its OWN batches
+    (replicas -- a batch is never split, its normalisation statistics are batch-wide), the embeddings of all ranks are
+    all-gathered, every rank searches all of them against its shard, and the partial results are exchanged and merged
+    by `EmbeddingBank.search`; each rank returns the rows of its own batch.  All ranks must feed the same number of
+    batches with the same number of embedding rows.
+
+    Ordering between the two streams is by events only; the host never waits inside the loop.  Candidate-buffer
+    overflow words are collected and checked once at the end; an affected batch is searched again with the checked
+    path (`EmbeddingBank.search(check=True)`).
+    """
+
+    def __init__(self, *, embedding_model: EmbeddingModule, bank: EmbeddingBank, k: int = 10, overlap: bool = True) -> None:
+        if not isinstance(k, int) or isinstance(k, bool) or k < 1:
+            raise ValueError(f"k must be a positive int, got {k!r}")
+        if embedding_model.embedding_dim != bank.dim:
+            raise ValueError(f"embedder produces {embedding_model.embedding_dim}-d vectors, the bank holds {bank.dim}-d rows")
+        self.embedding_model = embedding_model
+        self.bank = bank
+        self.k = k
+        self.overlap = overlap
+
+    def _queries(self, emb: EmbeddingBatch) -> Tensor:
+        """This rank's flat vectors in the bank dtype -- gathered over the ranks of a sharded bank."""
+        q = emb.get_flat_vectors().to(self.bank.dtype).contiguous()
+        group = self.bank.process_group
+        if group is None:
+            return q
+        world = dist.get_world_size(group)
+        on_host = dist.get_backend(group) == "gloo" and q.device.type != "cpu"
+        src = q.cpu() if on_host else q
+        gathered = torch.empty((world * src.shape[0], src.shape[1]), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(gathered, src, group=group)
+        return gathered.to(q.device)
+
+    def _own_rows(self, t: Tensor, rows: int) -> Tensor:
+        group = self.bank.process_group
+        if group is None:
+            return t
+        r = dist.get_rank(group)
+        return t[r * rows : (r + 1) * rows]
+
+    def run(self, dataloader: Iterable[ImageBatch]) -> list[SearchResult]:
+        """One `SearchResult` per input batch, in loader order."""
+        device = self.embedding_model.device
+        use_streams = self.overlap and device.type == "cuda"
+        if use_streams:
+            enc_stream, search_stream = torch.cuda.Stream(device), torch.cuda.Stream(device)
+            enc_stream.wait_stream(torch.cuda.current_stream(device))
+            search_stream.wait_stream(torch.cuda.current_stream(device))
+        pending: list[tuple[Tensor, int, Tensor, Tensor, Tensor, Tensor | None]] = []
+        for batch in dataloader:
+            batch = batch.to(device)
+            if use_streams:
+                enc_stream.wait_stream(torch.cuda.current_stream(device))  # the host-to-device copy of this batch
+                batch.images.record_stream(enc_stream)
+                with torch.cuda.stream(enc_stream):
+                    emb = self.embedding_model.predict_step(batch)
+                    q = self._queries(emb)
+                    ready = torch.cuda.Event()
+                    ready.record(enc_stream)
+                    rows = emb.get_flat_vectors().shape[0]
+                with torch.cuda.stream(search_stream):
+                    search_stream.wait_event(ready)
+                    q.record_stream(search_stream)
+                    scores, neighbours = self.bank.search(q, self.k, check=False)
+                    status = self.bank.last_status
+            else:
+                emb = self.embedding_model.predict_step(batch)
+                q = self._queries(emb)
+                rows = emb.get_flat_vectors().shape[0]
+                scores, neighbours = self.bank.search(q, self.k, check=False)
+                status = self.bank.last_status
+            pending.append((batch.indices, rows, q, scores, neighbours, status))
+        if use_streams:
+            torch.cuda.current_stream(device).wait_stream(enc_stream)
+            torch.cuda.current_stream(device).wait_stream(search_stream)
+        results = []
+        for indices, rows, q, scores, neighbours, status in pending:
+            overflowed = status is not None and int(status[0].item()) != 0
+            if self.bank.process_group is not None:  # every rank must take the same branch: agree on the flag
+                group = self.bank.process_group
+                flag = torch.tensor([int(overflowed)], dtype=torch.int32,
+                                    device="cpu" if dist.get_backend(group) == "gloo" else device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+                overflowed = bool(flag.item())
+            if overflowed:
+                scores, neighbours = self.bank.search(q, self.k, check=True)
+            results.append(SearchResult(indices=indices, scores=self._own_rows(scores, rows),
+                                        neighbours=self._own_rows(neighbours, rows)))
+        return results

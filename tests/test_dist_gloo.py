@@ -80,3 +80,66 @@ def test_sharded_search_equals_unsharded(world: int, n: int, k: int, tmp_path: P
         got = np.load(tmp_path / f"rank{rank}.npz")
         np.testing.assert_array_equal(got["indices"], exp_i)
         np.testing.assert_array_equal(got["scores"], exp_s)
+
+
+def _pipeline_worker(rank: int, world: int, port: int, n: int, k: int, out_dir: str) -> None:
+    """`EmbedSearchPipeline` over a 2-way sharded bank: each rank 'encodes' its own batches (a test double stands in
+    for the HIP embedder: fixed random projection of the mean pixel rows), the embeddings are all-gathered, searched
+    against every shard and each rank keeps the rows of its own batches."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cases
+        from imagescry_amd import EmbeddingBank, EmbeddingBatch, EmbeddingModule, EmbedSearchPipeline, ImageBatch
+        from oracle import search_oracle
+
+        class OracleBank(EmbeddingBank):
+            def _store(self, embeddings, normalize):
+                return embeddings.contiguous()
+
+            def _local_topk(self, queries, kk, check, out=None):
+                s, i = search_oracle.cosine_topk(self._bank, queries, kk, index_base=self.index_base)
+                return torch.from_numpy(s), torch.from_numpy(i)
+
+            def _merge_topk(self, scores, indices, kk):
+                s, i = search_oracle.topk_merge(scores.numpy(), indices.numpy(), kk)
+                return torch.from_numpy(s), torch.from_numpy(i)
+
+        class StubEmbedder(EmbeddingModule):
+            proj = torch.randn(3 * 8, 64, generator=torch.Generator().manual_seed(3))
+
+            def preprocess(self, images):
+                return images.float()
+
+            def forward(self, x):
+                return (x.mean(dim=3).flatten(1) @ self.proj)[:, :, None, None]
+
+            @property
+            def embedding_dim(self):
+                return 64
+
+            def predict_step(self, batch):
+                e = torch.nn.functional.normalize(self.forward(self.preprocess(batch.images)), dim=1)
+                return EmbeddingBatch(indices=batch.indices, embeddings=e)
+
+        bank, _ = cases.search_case(n, 64, 4, torch.float16, seed=8)
+        eb = OracleBank(bank, dtype=torch.float16, normalize=False, process_group=dist.group.WORLD)
+        g = torch.Generator().manual_seed(100 + rank)
+        batches = [ImageBatch(indices=torch.arange(5) + 10 * b + 100 * rank,
+                              images=torch.randint(0, 256, (5, 3, 8, 6), dtype=torch.uint8, generator=g)) for b in range(3)]
+        model = StubEmbedder()
+        results = EmbedSearchPipeline(embedding_model=model, bank=eb, k=k).run(batches)
+        assert len(results) == 3
+        for b, r in zip(batches, results):
+            assert torch.equal(r.indices, b.indices) and r.scores.shape == (5, k)
+            q = model.predict_step(b).get_flat_vectors().half()
+            exp_s, exp_i = search_oracle.cosine_topk(bank, q, k)  # unsharded answer for this rank's own images
+            np.testing.assert_array_equal(r.neighbours.numpy(), exp_i)
+            np.testing.assert_array_equal(r.scores.numpy(), exp_s)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_embed_search_pipeline_two_ranks(tmp_path: Path) -> None:
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), 333, 7, str(tmp_path)), nprocs=2, join=True)
