@@ -21,6 +21,7 @@ ISC_U8, ISC_F16, ISC_F32 = 0, 1, 2
 ISC_ACT_NONE, ISC_ACT_RELU, ISC_ACT_GELU, ISC_ACT_SILU, ISC_ACT_SIGMOID = 0, 1, 2, 3, 4
 ISC_ACT_RESIDUAL_AFTER = 0x100
 ISC_TOPK_MAX_K = 120
+ISC_GEMM_A_PACKED, ISC_GEMM_W_PACKED, ISC_GEMM_OUT_PACKED, ISC_GEMM_TILE_256 = 1, 2, 4, 8
 ISC_KERNEL_DOTS_FILTER, ISC_KERNEL_CONV, ISC_KERNEL_GEMM_F16 = 0, 1, 2
 
 ISC_OK = 0
@@ -87,14 +88,14 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "isc_global_avgpool_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isc_gemm_f16": (
         c_int,
-        [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p],
+        [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p],
     ),
     "isc_layernorm": (
         c_int,
-        [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int64, c_void_p],
+        [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int64, c_int, c_void_p],
     ),
-    "isc_attention_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "isc_patchify_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isc_attention_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "isc_patchify_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "isc_vit_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isc_cosine_topk_workspace_bytes": (c_int, [c_int, c_int64, c_int, c_int, c_int, POINTER(c_size_t)]),
     "isc_cosine_topk": (

@@ -3,6 +3,8 @@
 //
 // Numerics: every product is fp16 x fp16 accumulated in float32 (v_mfma_f32_16x16x32_f16); the residual stream,
 // LayerNorm statistics, softmax statistics, bias and GELU are float32.  Only GEMM operands are rounded to fp16.
+#include <stdlib.h>
+
 #include "isc_common.h"
 
 namespace {
@@ -12,6 +14,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+// Direct global -> LDS copy (LDS-DMA): lane l of the wave writes 16 bytes at lds_wave_base + 16 * l.
+__device__ __forceinline__ void g2_dma16(const unsigned char* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
@@ -31,7 +39,47 @@ struct GemmParams {
     void* out;
     long long M;
     int N, K, ksteps, act, out_f32;
+    int a_packed, w_packed, out_packed;  // operand / fp16 output in the K-step-major tile layout (see pk_offset)
 };
+
+// The PACKED fp16 matrix layout (the embedding bank's layout, bank_layout.h): rows in tiles of 256, columns in K steps of
+// 64 halves, stored [tile][K step][row][64 halves].  The 256 x 128 B block one K step of one tile needs is 32 KiB of
+// contiguous memory, so a GEMM's operand stream uses every L2 channel; with row-major operands the 128-byte pieces of a
+// K step are a whole row (1.5 - 6 KiB) apart and land on 2 - 8 of the 16 channels.
+__host__ __device__ __forceinline__ size_t pk_offset(long long row, int col, int cols) {
+    return (((size_t)(row >> 8) * (size_t)(cols >> 6) + (size_t)(col >> 6)) * 256 + (size_t)(row & 255)) * 64 + (size_t)(col & 63);
+}
+// byte offset of the first K step of `row`, and the byte distance between consecutive K steps of a row
+__device__ __forceinline__ size_t operand_row_bytes(long long row, int K, int packed) {
+    return packed ? pk_offset(row, 0, K) * 2 : (size_t)row * (size_t)K * 2;
+}
+__device__ __forceinline__ int operand_kstride(int packed) { return packed ? 32768 : 128; }
+
+// Workgroup id -> output tile, XCD-aware.  Workgroup i runs on XCD i % 8 and every XCD has its own 4 MiB L2, so the
+// tiles are ordered band-major -- bands of `band` token tiles; inside a band the feature tile is the slow index and the
+// token tile the fast one -- and that sequence is cut into 8 contiguous slices, one per XCD (grid = 8 * ceil(T / 8),
+// surplus workgroups return).  A band's activation rows (<= ~2 MiB) then stay in ONE L2 while the weight tiles pass
+// by once per band; with the plain (token tile, feature tile) order every XCD streams every activation tile and the
+// whole weight matrix (3.5 - 4.7 MiB for ViT-B: more than an L2) over and over from the Infinity Cache.
+template <int TM_, int TN_>
+__device__ __forceinline__ bool gemm_tile(const GemmParams& p, long long& m0, int& n0) {
+    const long long mt = (p.M + TM_ - 1) / TM_;
+    const int nt = (p.N + TN_ - 1) / TN_;
+    const long long total = mt * nt;
+    const long long slice = (total + 7) / 8;
+    const long long t = (long long)(blockIdx.x & 7) * slice + (blockIdx.x >> 3);
+    if ((long long)(blockIdx.x >> 3) >= slice || t >= total) return false;
+    int band = (int)((2 << 20) / ((long long)TM_ * p.K * 2));
+    band = band < 1 ? 1 : band > 16 ? 16 : band;
+    const long long per_band = (long long)band * nt;
+    const long long b = t / per_band;
+    const long long t_in = t - b * per_band;
+    const long long left = mt - b * band;
+    const int mb = (int)(left < band ? left : band);
+    n0 = (int)(t_in / mb) * TN_;
+    m0 = (b * band + t_in % mb) * TM_;
+    return true;
+}
 
 template <int TN, int TM>
 __global__ __launch_bounds__(256, 2) void k_gemm_f16(const GemmParams p) {
@@ -48,22 +96,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16(const GemmParams p) {
     const int wave = tid >> 6;
     const int wn = wave % WN;
     const int wm = wave / WN;
-    const int n_tiles = (p.N + TN - 1) / TN;
-    const int n0 = (int)(blockIdx.x % n_tiles) * TN;  // feature tile fastest: one token tile is re-read back to back
-    const long long m0 = (long long)(blockIdx.x / n_tiles) * TM;
+    long long m0;
+    int n0;
+    if (!gemm_tile<TM, TN>(p, m0, n0)) return;
 
     const int srow = tid >> 3;
     const int lchunk = (tid & 7) ^ ((srow >> 1) & 7);
-    const _Float16* a_ptr[NA];
-    const _Float16* b_ptr[NB];
+    const unsigned char* a_ptr[NA];
+    const unsigned char* b_ptr[NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) a_ptr[i] = p.w + (size_t)min(n0 + srow + 32 * i, p.N - 1) * p.K + lchunk * 8;
+    for (int i = 0; i < NA; ++i)
+        a_ptr[i] = reinterpret_cast<const unsigned char*>(p.w) +
+                   operand_row_bytes(min(n0 + srow + 32 * i, p.N - 1), p.K, p.w_packed) + lchunk * 16;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         long long m = m0 + srow + 32 * i;
         if (m > p.M - 1) m = p.M - 1;
-        b_ptr[i] = p.a + (size_t)m * p.K + lchunk * 8;
+        b_ptr[i] = reinterpret_cast<const unsigned char*>(p.a) + operand_row_bytes(m, p.K, p.a_packed) + lchunk * 16;
     }
+    const int a_kstride = operand_kstride(p.w_packed), b_kstride = operand_kstride(p.a_packed);
 
     const int frow = lane & 15;
     const int fg = lane >> 4;
@@ -85,9 +136,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16(const GemmParams p) {
     u32x4 sa[NA], sb[NB];
     auto load_step = [&](int ks) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) sa[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + ks * 64);
+        for (int i = 0; i < NA; ++i) sa[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + (size_t)ks * a_kstride);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) sb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + ks * 64);
+        for (int i = 0; i < NB; ++i) sb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + (size_t)ks * b_kstride);
     };
     auto store_step = [&](int buf) {
         unsigned char* a = lds + buf * BUF_BYTES + tid * 16;
@@ -146,7 +197,382 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16(const GemmParams p) {
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
             } else {
                 half4 h = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(p.out) + o) = h;
+                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(p.out) + (p.out_packed ? pk_offset(m, n, p.N) : o)) = h;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same 128 x 128 tile staged by LDS-DMA instead of registers.  A `ds_write_b128` costs 13 LDS cycles per wave
+// instruction (the VGPR -> LDS transfer, MI355X_MICROARCH.md "LDS"), so the register-staged kernel above spends about as
+// long storing a K step into LDS as the matrix cores need for it; `global_load_lds_dwordx4` writes the LDS directly.
+// Two stages of 32 KiB per workgroup (two workgroups per CU): iteration s issues the DMA of step s + 1, computes step
+// s from fragments read with inline-asm `ds_read_b128` (a C++ LDS load would make hipcc drain the DMA first), then
+// vmcnt(0) + one barrier.  The second workgroup on the CU covers the wait.
+#define G1_DS_READ(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_))
+
+// DBG (ISC_GEMM_DEBUG, bring-up only, wrong results): 1 = no DMA after the prologue, 2 = no fragment reads, 3 = no MFMAs,
+// 4 = no epilogue (nothing stored).
+template <int DBG>
+__global__ __launch_bounds__(256, 2) void k_gemm_f16_dma(const GemmParams p) {
+    constexpr int STAGE = 32768;  // [weights 128 rows | activations 128 rows] x 128 B
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1;
+    const int wm = wave >> 1;
+    long long m0;
+    int n0;
+    if (!gemm_tile<128, 128>(p, m0, n0)) return;
+    const int ksteps = p.ksteps;
+
+    // LDS-DMA assignment: wave w copies rows [32 w, 32 w + 32) of both operand tiles, 8 rows (1 KiB) per instruction
+    const unsigned char* wsrc[4];
+    const unsigned char* xsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wave * 32 + j * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        const long long xr = m0 + r < p.M ? m0 + r : p.M - 1;
+        wsrc[j] = reinterpret_cast<const unsigned char*>(p.w) + operand_row_bytes(min(n0 + r, p.N - 1), p.K, p.w_packed) + lc * 16;
+        xsrc[j] = reinterpret_cast<const unsigned char*>(p.a) + operand_row_bytes(xr, p.K, p.a_packed) + lc * 16;
+    }
+    const int w_kstride = operand_kstride(p.w_packed), x_kstride = operand_kstride(p.a_packed);
+    unsigned char* dma_dst = lds + wave * 4096;  // + stage, + 16 KiB for the activation half, + 1024 j
+
+    auto issue = [&](int ks, int stage) {
+        unsigned char* d = dma_dst + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g2_dma16(wsrc[j] + (size_t)ks * w_kstride, d + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g2_dma16(xsrc[j] + (size_t)ks * x_kstride, d + 16384 + j * 1024);
+    };
+
+    const int frow = lane & 15;
+    const int fg = lane >> 4;
+    const int fsw = (lane >> 1) & 7;
+    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned a_frag0 = lds_addr + wn * 8192 + frow * 128 + (((0 + fg) ^ fsw) << 4);
+    const unsigned a_frag1 = lds_addr + wn * 8192 + frow * 128 + (((4 + fg) ^ fsw) << 4);
+    const unsigned b_frag0 = lds_addr + 16384 + wm * 8192 + frow * 128 + (((0 + fg) ^ fsw) << 4);
+    const unsigned b_frag1 = lds_addr + 16384 + wm * 8192 + frow * 128 + (((4 + fg) ^ fsw) << 4);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int s = 0; s < ksteps; ++s) {
+        const unsigned st = (unsigned)(s & 1) * STAGE;
+        if (DBG != 1 && s + 1 < ksteps) issue(s + 1, (s + 1) & 1);
+        u32x4 a0[4], b0[4], a1[4], b1[4];
+        const unsigned aa0 = a_frag0 + st, bb0 = b_frag0 + st, aa1 = a_frag1 + st, bb1 = b_frag1 + st;
+        if (DBG == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a0[i] = b0[i] = a1[i] = b1[i] = u32x4{(unsigned)s, 1u, (unsigned)lane, 3u};
+        } else {
+        G1_DS_READ(a0[0], aa0, 0);
+        G1_DS_READ(a0[1], aa0, 2048);
+        G1_DS_READ(a0[2], aa0, 4096);
+        G1_DS_READ(a0[3], aa0, 6144);
+        G1_DS_READ(b0[0], bb0, 0);
+        G1_DS_READ(b0[1], bb0, 2048);
+        G1_DS_READ(b0[2], bb0, 4096);
+        G1_DS_READ(b0[3], bb0, 6144);
+        G1_DS_READ(a1[0], aa1, 0);
+        G1_DS_READ(a1[1], aa1, 2048);
+        G1_DS_READ(a1[2], aa1, 4096);
+        G1_DS_READ(a1[3], aa1, 6144);
+        G1_DS_READ(b1[0], bb1, 0);
+        G1_DS_READ(b1[1], bb1, 2048);
+        G1_DS_READ(b1[2], bb1, 4096);
+        G1_DS_READ(b1[3], bb1, 6144);
+        }
+        asm volatile("s_waitcnt lgkmcnt(8)"
+                     : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG == 3) {
+            acc[0][0][0] += __uint_as_float(a0[0][0] ^ b0[1][1] ^ a1[2][2] ^ b1[3][3]);
+        } else {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a0[mi]),
+                                                                     __builtin_bit_cast(half8, b0[ni]), acc[mi][ni], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG != 3) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a1[mi]),
+                                                                     __builtin_bit_cast(half8, b1[ni]), acc[mi][ni], 0, 0, 0);
+        }
+        // this wave's DMA of step s + 1 has landed; the barrier publishes every wave's pieces and guarantees that nobody
+        // still reads the stage the next iteration refills
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (DBG == 4) {  // keep the accumulators alive without the store tail
+        float t = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) t += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+        if (t == 123.456f) reinterpret_cast<float*>(p.out)[0] = t;
+        return;
+    }
+    f32x4 bias[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int n = n0 + wn * 64 + mi * 16 + fg * 4;
+        bias[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bias[mi] = *reinterpret_cast<const f32x4*>(p.bias + n);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const long long m = m0 + wm * 64 + ni * 16 + frow;
+        if (m >= p.M) continue;
+        f32x4 r[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int n = n0 + wn * 64 + mi * 16 + fg * 4;
+            r[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.res && n < p.N) r[mi] = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.N + n);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int n = n0 + wn * 64 + mi * 16 + fg * 4;
+            if (n >= p.N) continue;
+            f32x4 v = acc[mi][ni] + bias[mi];
+            if (p.act == ISC_ACT_GELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+            }
+            v += r[mi];
+            const size_t o = (size_t)m * p.N + n;
+            if (p.out_f32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
+            } else {
+                half4 h = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(p.out) + (p.out_packed ? pk_offset(m, n, p.N) : o)) = h;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The large-problem variant: 256 x 256 tile, FOUR waves (one per SIMD), each owning a 128 x 128 sub-tile.
+//
+// Why.  With 64 x 64 (or 128 x 64) wave tiles every MFMA needs 0.5 (0.375) fragment reads and the LDS -- 128 B/clk
+// per CU -- has to run at 100 % duty for the matrix pipe to do so (the co-limit measured on k_dots_filter).  A
+// 128 x 128 wave tile needs 16 + 16 reads per 128 MFMAs: 64 B/clk of reads plus 32 B/clk of DMA writes = 75 % duty.
+// The price is 256 accumulator registers (AGPRs), i.e. one wave per SIMD, so nothing but this wave's own instruction
+// stream can hide latency: fragment reads for the NEXT half K step and the LDS-DMA of LATER K steps are issued
+// between the MFMAs of the current half step, four MFMAs per slot.
+//
+// LDS = a ring of 2 weight stages and 3 activation stages of 32 KiB (all 160 KiB).  Weights are L2 resident
+// (prefetch distance 1 K step), activations stream from HBM (distance 2).  One barrier per K step, placed BETWEEN
+// the two half steps: at that point every wave holds the second half's fragments in registers, so the stages of
+// step s are free and those of step s + 1 have landed.
+//
+//   step s:  [64 MFMAs on half 0 | reads of half 1]  wait, barrier  [64 MFMAs on half 1 | reads of step s+1 half 0,
+//                                                                    DMA of weights s+2 and activations s+3]
+#define G2_DS_READ(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_))
+
+
+// DBG is a bring-up aid (ISC_GEMM_DEBUG, never set in production; results are wrong for DBG != 0): 1 = no LDS-DMA after
+// the prologue, 2 = no fragment reads in the loop, 3 = no MFMAs.
+template <int DBG>
+__global__ __launch_bounds__(256, 1) void k_gemm_f16_big(const GemmParams p) {
+    constexpr int STAGE = 32768;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[5 * STAGE];  // [W0 W1 | X0 X1 X2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1;
+    const int wm = wave >> 1;
+    long long m0;
+    int n0;
+    if (!gemm_tile<256, 256>(p, m0, n0)) return;
+    const int ksteps = p.ksteps;
+
+    // ---- LDS-DMA assignment: wave w copies rows [64 w, 64 w + 64) of both operand tiles, 8 rows (1 KiB) per instruction
+    unsigned woff[8], xoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = wave * 64 + j * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        const int wr = min(n0 + r, p.N - 1);
+        const long long xr = m0 + r < p.M ? m0 + r : p.M - 1;
+        woff[j] = (unsigned)operand_row_bytes(wr, p.K, p.w_packed) + lc * 16;
+        xoff[j] = (unsigned)operand_row_bytes(xr, p.K, p.a_packed) + lc * 16;
+    }
+    const int w_kstride = operand_kstride(p.w_packed), x_kstride = operand_kstride(p.a_packed);
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w);
+    const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(p.a);
+    unsigned char* dma_dst = lds + wave * 8192;  // + stage base + 1024 j
+
+    // ---- fragment addresses
+    const int frow = lane & 15;
+    const int fg = lane >> 4;
+    const int fsw = (lane >> 1) & 7;
+    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned a_frag0 = lds_addr + wn * 16384 + frow * 128 + (((0 + fg) ^ fsw) << 4);
+    const unsigned a_frag1 = lds_addr + wn * 16384 + frow * 128 + (((4 + fg) ^ fsw) << 4);
+    const unsigned b_frag0 = lds_addr + 2 * STAGE + wm * 16384 + frow * 128 + (((0 + fg) ^ fsw) << 4);
+    const unsigned b_frag1 = lds_addr + 2 * STAGE + wm * 16384 + frow * 128 + (((4 + fg) ^ fsw) << 4);
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define G2_DMA_W(ks_, stage_, j_) \
+    g2_dma16(wsrc + woff[j_] + (size_t)(ks_) * w_kstride, dma_dst + (stage_) * STAGE + (j_) * 1024)
+#define G2_DMA_X(ks_, stage_, j_) \
+    g2_dma16(xsrc + xoff[j_] + (size_t)(ks_) * x_kstride, dma_dst + (2 + (stage_)) * STAGE + (j_) * 1024)
+
+    // ---- prologue.  DMA stream order (the counted vmcnt below relies on it): W0 X0 | X1 W1 | X2
+#pragma unroll
+    for (int j = 0; j < 8; ++j) G2_DMA_W(0, 0, j);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) G2_DMA_X(0, 0, j);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) G2_DMA_X(1, 1, j);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) G2_DMA_W(1, 1, j);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) G2_DMA_X(2, 2, j);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    u32x4 a0[8], b0[8], a1[8], b1[8];
+    G2_DS_READ(a0[0], a_frag0, 0);
+    G2_DS_READ(a0[1], a_frag0, 2048);
+    G2_DS_READ(a0[2], a_frag0, 4096);
+    G2_DS_READ(a0[3], a_frag0, 6144);
+    G2_DS_READ(a0[4], a_frag0, 8192);
+    G2_DS_READ(a0[5], a_frag0, 10240);
+    G2_DS_READ(a0[6], a_frag0, 12288);
+    G2_DS_READ(a0[7], a_frag0, 14336);
+    G2_DS_READ(b0[0], b_frag0, 0);
+    G2_DS_READ(b0[1], b_frag0, 2048);
+    G2_DS_READ(b0[2], b_frag0, 4096);
+    G2_DS_READ(b0[3], b_frag0, 6144);
+    G2_DS_READ(b0[4], b_frag0, 8192);
+    G2_DS_READ(b0[5], b_frag0, 10240);
+    G2_DS_READ(b0[6], b_frag0, 12288);
+    G2_DS_READ(b0[7], b_frag0, 14336);
+#define G2_WAIT_LGKM0(a_, b_)                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                           \
+                 : "+v"(a_[0]), "+v"(a_[1]), "+v"(a_[2]), "+v"(a_[3]), "+v"(a_[4]), "+v"(a_[5]), "+v"(a_[6]),     \
+                   "+v"(a_[7]));                                                                                  \
+    asm volatile(""                                                                                               \
+                 : "+v"(b_[0]), "+v"(b_[1]), "+v"(b_[2]), "+v"(b_[3]), "+v"(b_[4]), "+v"(b_[5]), "+v"(b_[6]),     \
+                   "+v"(b_[7]));                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);
+    G2_WAIT_LGKM0(a0, b0)
+
+#define G2_MFMA4(a_, b_, i_, jh_)                                                                                   \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) acc[i_][(jh_)*4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16( \
+        __builtin_bit_cast(half8, a_[i_]), __builtin_bit_cast(half8, b_[(jh_)*4 + jj]), acc[i_][(jh_)*4 + jj], 0, 0, 0);
+
+    int ws = 0, xs = 0;  // stages holding step s
+    for (int s = 0; s < ksteps; ++s) {
+        const unsigned wst = (unsigned)ws * STAGE, xst = (unsigned)xs * STAGE;
+        const unsigned a_addr1 = a_frag1 + wst, b_addr1 = b_frag1 + xst;
+        // ---- half 0 on the matrix cores; half 1's fragments on their way
+#define G2_SLOT1(x_)                                                          \
+    if (DBG != 2) {                                                           \
+        if ((x_) < 8) { G2_DS_READ(a1[(x_)&7], a_addr1, ((x_)&7) * 2048); }    \
+        else { G2_DS_READ(b1[(x_)&7], b_addr1, ((x_)&7) * 2048); }             \
+    }                                                                         \
+    if (DBG != 3) { G2_MFMA4(a0, b0, (x_) >> 1, (x_)&1) }                      \
+    __builtin_amdgcn_sched_barrier(0);
+        G2_SLOT1(0) G2_SLOT1(1) G2_SLOT1(2) G2_SLOT1(3) G2_SLOT1(4) G2_SLOT1(5) G2_SLOT1(6) G2_SLOT1(7)
+        G2_SLOT1(8) G2_SLOT1(9) G2_SLOT1(10) G2_SLOT1(11) G2_SLOT1(12) G2_SLOT1(13) G2_SLOT1(14) G2_SLOT1(15)
+#undef G2_SLOT1
+        G2_WAIT_LGKM0(a1, b1)
+        // everything of step s + 1 has to be in LDS; the newest DMA group (activations of step s + 2) may stay in flight
+        if (s + 2 < ksteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- half 1 on the matrix cores; next step's half 0 fragments and the DMA of later steps on their way
+        const int ws_n = ws ^ 1, xs_n = xs == 2 ? 0 : xs + 1;
+        const unsigned a_addr0 = a_frag0 + (unsigned)ws_n * STAGE, b_addr0 = b_frag0 + (unsigned)xs_n * STAGE;
+        const bool do_w = DBG != 1 && s + 2 < ksteps, do_x = DBG != 1 && s + 3 < ksteps;
+#define G2_SLOT2(x_)                                                          \
+    if ((x_) < 8) {                                                           \
+        if (DBG != 2) { G2_DS_READ(a0[(x_)&7], a_addr0, ((x_)&7) * 2048); }    \
+        if (do_w) G2_DMA_W(s + 2, ws, (x_)&7);                                 \
+    } else {                                                                  \
+        if (DBG != 2) { G2_DS_READ(b0[(x_)&7], b_addr0, ((x_)&7) * 2048); }    \
+        if (do_x) G2_DMA_X(s + 3, xs, (x_)&7);                                 \
+    }                                                                         \
+    if (DBG != 3) { G2_MFMA4(a1, b1, (x_) >> 1, (x_)&1) }                      \
+    __builtin_amdgcn_sched_barrier(0);
+        G2_SLOT2(0) G2_SLOT2(1) G2_SLOT2(2) G2_SLOT2(3) G2_SLOT2(4) G2_SLOT2(5) G2_SLOT2(6) G2_SLOT2(7)
+        G2_SLOT2(8) G2_SLOT2(9) G2_SLOT2(10) G2_SLOT2(11) G2_SLOT2(12) G2_SLOT2(13) G2_SLOT2(14) G2_SLOT2(15)
+#undef G2_SLOT2
+        G2_WAIT_LGKM0(a0, b0)
+        ws = ws_n;
+        xs = xs_n;
+    }
+#undef G2_MFMA4
+#undef G2_WAIT_LGKM0
+#undef G2_DMA_W
+#undef G2_DMA_X
+
+    // the bias is added here, not used to initialise the accumulators: a load in front of the DMA prologue would put
+    // its vmcnt wait in the middle of it
+    f32x4 bias[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = n0 + wn * 128 + i * 16 + fg * 4;
+        bias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bias[i] = *reinterpret_cast<const f32x4*>(p.bias + n);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long m = m0 + wm * 128 + j * 16 + frow;
+        if (m >= p.M) continue;
+        f32x4 r[8];  // the eight residual loads of this token go out together, then the eight stores
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = n0 + wn * 128 + i * 16 + fg * 4;
+            r[i] = bias[i];
+            if (p.res && n < p.N) r[i] += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.N + n);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = n0 + wn * 128 + i * 16 + fg * 4;
+            if (n >= p.N) continue;
+            const f32x4 v = acc[i][j] + r[i];
+            const size_t o = (size_t)m * p.N + n;
+            if (p.out_f32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
+            } else {
+                half4 h = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(p.out) + (p.out_packed ? pk_offset(m, n, p.N) : o)) = h;
             }
         }
     }
@@ -158,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16(const GemmParams p) {
 template <bool OUT_F32, int NV>
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, long long rows, int D, long long ldx,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   float eps, void* __restrict__ y, long long ldy) {
+                                                   float eps, void* __restrict__ y, long long ldy, int y_packed) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -200,21 +626,22 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + (size_t)row * ldy + 4 * c) = o;
         } else {
             half4 h = half4{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
-            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(y) + (size_t)row * ldy + 4 * c) = h;
+            const size_t at = y_packed ? pk_offset(row, 4 * c, D) : (size_t)row * ldy + 4 * c;
+            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(y) + at) = h;
         }
     }
 }
 
 template <bool OUT_F32>
 void launch_layernorm(int nv, dim3 grid, hipStream_t s, const float* x, long long rows, int D, long long ldx,
-                      const float* gamma, const float* beta, float eps, void* y, long long ldy) {
+                      const float* gamma, const float* beta, float eps, void* y, long long ldy, int y_packed) {
     // NV = 16-byte vectors per lane: the smallest instantiation that covers D keeps the register count (and so the
     // number of rows in flight per CU) where this bandwidth-bound kernel needs it
-    if (nv <= 1) hipLaunchKernelGGL((k_layernorm<OUT_F32, 1>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy);
-    else if (nv <= 2) hipLaunchKernelGGL((k_layernorm<OUT_F32, 2>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy);
-    else if (nv <= 3) hipLaunchKernelGGL((k_layernorm<OUT_F32, 3>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy);
-    else if (nv <= 4) hipLaunchKernelGGL((k_layernorm<OUT_F32, 4>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy);
-    else hipLaunchKernelGGL((k_layernorm<OUT_F32, 8>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy);
+    if (nv <= 1) hipLaunchKernelGGL((k_layernorm<OUT_F32, 1>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy, y_packed);
+    else if (nv <= 2) hipLaunchKernelGGL((k_layernorm<OUT_F32, 2>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy, y_packed);
+    else if (nv <= 3) hipLaunchKernelGGL((k_layernorm<OUT_F32, 3>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy, y_packed);
+    else if (nv <= 4) hipLaunchKernelGGL((k_layernorm<OUT_F32, 4>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy, y_packed);
+    else hipLaunchKernelGGL((k_layernorm<OUT_F32, 8>), grid, dim3(256), 0, s, x, rows, D, ldx, gamma, beta, eps, y, ldy, y_packed);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -236,6 +663,7 @@ constexpr int ATT_KSTRIDE = 72;   // halves per key row (64 + 8 pad)
 constexpr int ATT_VSTRIDE = 232;  // halves per value^T row (224 + 8 pad)
 constexpr int ATT_THREADS = 512;
 
+template <bool PACKED>
 __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* __restrict__ qkv, int T, int heads,
                                                                 _Float16* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) _Float16 Ks[ATT_TMAX * ATT_KSTRIDE];
@@ -246,14 +674,20 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
     const size_t row_stride = (size_t)3 * D;
     const _Float16* base = qkv + (size_t)b * T * row_stride + h * 64;
     const int tid = threadIdx.x;
+    // element address of (token t of this image, part 0/1/2 = q/k/v, 8-half chunk c of this head).  In the packed
+    // layout a head's 64 values are exactly one 128-byte K-step segment of the token's row.
+    auto qkv_at = [&](int t, int part, int c) -> const _Float16* {
+        if (PACKED) return qkv + pk_offset((long long)b * T + t, part * D + h * 64, 3 * D) + c * 8;
+        return base + (size_t)t * row_stride + part * D + c * 8;
+    };
 
     for (int i = tid; i < ATT_TMAX * 8; i += ATT_THREADS) {
         const int t = i >> 3, c = i & 7;
         half8 kv = half8{0, 0, 0, 0, 0, 0, 0, 0};
         half8 vv = kv;
         if (t < T) {
-            kv = *reinterpret_cast<const half8*>(base + (size_t)t * row_stride + D + c * 8);
-            vv = *reinterpret_cast<const half8*>(base + (size_t)t * row_stride + 2 * D + c * 8);
+            kv = *reinterpret_cast<const half8*>(qkv_at(t, 1, c));
+            vv = *reinterpret_cast<const half8*>(qkv_at(t, 2, c));
         }
         *reinterpret_cast<half8*>(&Ks[t * ATT_KSTRIDE + c * 8]) = kv;
 #pragma unroll
@@ -268,11 +702,10 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
     const int nqb = (T + 15) >> 4;
     for (int qb = wave; qb < nqb; qb += ATT_THREADS / 64) {
         const int tq = qb * 16 + qi;
-        const _Float16* qrow = base + (size_t)min(tq, T - 1) * row_stride;
         half8 qf[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            qf[kk] = *reinterpret_cast<const half8*>(qrow + (kk * 4 + g) * 8);
+            qf[kk] = *reinterpret_cast<const half8*>(qkv_at(min(tq, T - 1), 0, kk * 4 + g));
 #pragma unroll
             for (int j = 0; j < 8; ++j) qf[kk][j] = qf[kk][j] * (_Float16)0.125f;  // 1/sqrt(64): exact scaling
         }
@@ -331,7 +764,8 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
             __builtin_amdgcn_sched_barrier(0);
         }
         if (tq < T) {
-            _Float16* orow = out + ((size_t)b * T + tq) * D + h * 64;
+            _Float16* orow = PACKED ? out + pk_offset((long long)b * T + tq, h * 64, D)
+                                    : out + ((size_t)b * T + tq) * D + h * 64;
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
                 half4 hv;
@@ -346,7 +780,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
 // ---------------------------------------------------------------------------------------------------------
 // patches[b * gh * gw + (ph * gw + pw)][c * P * P + r * P + s] = fp16(x[b][c][ph * P + r][pw * P + s]); 8 values a thread
 __global__ __launch_bounds__(256) void k_patchify_f16(const float* __restrict__ x, int C, int H, int W, int P,
-                                                      size_t total8, _Float16* __restrict__ y) {
+                                                      size_t total8, _Float16* __restrict__ y, int packed) {
     const int gw = W / P, gh = H / P;
     const int pv = P / 8;
     const int kdim = C * P * P;
@@ -366,7 +800,8 @@ __global__ __launch_bounds__(256) void k_patchify_f16(const float* __restrict__ 
         half8 o = half8{(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3],
                         (_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
         const size_t m = (b * gh + ph) * gw + pw;
-        *reinterpret_cast<half8*>(y + m * kdim + (c * P + r) * P + s) = o;
+        const int k = (c * P + r) * P + s;
+        *reinterpret_cast<half8*>(y + (packed ? pk_offset((long long)m, k, kdim) : m * kdim + k)) = o;
     }
 }
 
@@ -395,11 +830,13 @@ int grid_for(size_t work_items) {
 }  // namespace
 
 extern "C" int isc_gemm_f16(const void* a, int64_t M, int K, const void* w, int N, const float* bias,
-                            const float* residual, int act, void* out, int out_dtype, void* stream) {
+                            const float* residual, int act, void* out, int out_dtype, int flags, void* stream) {
     ISC_REQUIRE(a && w && out && M > 0 && K > 0 && N > 0);
     ISC_REQUIRE(act == ISC_ACT_NONE || act == ISC_ACT_GELU);
     ISC_REQUIRE(out_dtype == ISC_F16 || out_dtype == ISC_F32);
+    ISC_REQUIRE((flags & ~(ISC_GEMM_A_PACKED | ISC_GEMM_W_PACKED | ISC_GEMM_OUT_PACKED | ISC_GEMM_TILE_256)) == 0);
     if (K % 64 != 0 || N % 4 != 0) return ISC_ERR_UNSUPPORTED;
+    if ((flags & ISC_GEMM_OUT_PACKED) && (out_dtype != ISC_F16 || N % 64 != 0)) return ISC_ERR_UNSUPPORTED;
     if (!isc_aligned(a, 16) || !isc_aligned(w, 16) || !isc_aligned(out, 16) || (bias && !isc_aligned(bias, 16)) ||
         (residual && !isc_aligned(residual, 16)))
         return ISC_ERR_ALIGNMENT;
@@ -415,20 +852,60 @@ extern "C" int isc_gemm_f16(const void* a, int64_t M, int K, const void* w, int 
     p.ksteps = K / 64;
     p.act = act;
     p.out_f32 = out_dtype == ISC_F32;
+    p.a_packed = (flags & ISC_GEMM_A_PACKED) != 0;
+    p.w_packed = (flags & ISC_GEMM_W_PACKED) != 0;
+    p.out_packed = (flags & ISC_GEMM_OUT_PACKED) != 0;
     const long long tiles = isc_ceil_div<long long>(M, 128) * isc_ceil_div<long long>(N, 128);
-    if (tiles > 0x7fffffffLL) return ISC_ERR_UNSUPPORTED;
+    if (tiles > 0x7ffffff0LL) return ISC_ERR_UNSUPPORTED;
     hipStream_t s = isc_stream(stream);
+    // ISC_GEMM_TILE_256 selects the 256 x 256 / one-wave-per-SIMD kernel explicitly (it measures the same as the
+    // 128 x 128 kernel on the ViT shapes -- both are bound by operand staging, DESIGN.md 4.3 -- so nothing picks it
+    // by default); its 32-bit DMA offsets bound the operand sizes and it has no activation epilogue
+    const bool big = (flags & ISC_GEMM_TILE_256) != 0;
+    if (big && (p.ksteps < 3 || act != ISC_ACT_NONE || (unsigned long long)(M + 255) * K * 2 >= (1ull << 32) ||
+                (unsigned long long)(N + 255) * K * 2 >= (1ull << 32)))
+        return ISC_ERR_UNSUPPORTED;
     isc_timing_begin(ISC_KERNEL_GEMM_F16, s);
-    hipLaunchKernelGGL((k_gemm_f16<128, 128>), dim3((unsigned)tiles), dim3(256), 0, s, p);
+    if (big) {
+        const long long tiles2 = isc_ceil_div<long long>(M, 256) * isc_ceil_div<long long>(N, 256);
+        const long long grid2 = isc_ceil_div<long long>(tiles2, 8) * 8;  // gemm_tile: 8 equal slices, one per XCD
+        static const int dbg = [] {
+            const char* e = getenv("ISC_GEMM_DEBUG");
+            return e ? atoi(e) : 0;
+        }();
+        if (dbg == 1) hipLaunchKernelGGL(k_gemm_f16_big<1>, dim3((unsigned)grid2), dim3(256), 0, s, p);
+        else if (dbg == 2) hipLaunchKernelGGL(k_gemm_f16_big<2>, dim3((unsigned)grid2), dim3(256), 0, s, p);
+        else if (dbg == 3) hipLaunchKernelGGL(k_gemm_f16_big<3>, dim3((unsigned)grid2), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(k_gemm_f16_big<0>, dim3((unsigned)grid2), dim3(256), 0, s, p);
+    } else {
+        static const bool regs = [] {
+            const char* e = getenv("ISC_GEMM_KERNEL");  // A/B aid: "regs" = the register-staged 128 x 128 kernel
+            return e && e[0] == 'r';
+        }();
+        const long long grid1 = isc_ceil_div<long long>(tiles, 8) * 8;
+        if (regs) hipLaunchKernelGGL((k_gemm_f16<128, 128>), dim3((unsigned)grid1), dim3(256), 0, s, p);
+        else {
+            static const int dbg1 = [] {
+                const char* e = getenv("ISC_GEMM_DEBUG");
+                return e ? atoi(e) : 0;
+            }();
+            if (dbg1 == 1) hipLaunchKernelGGL(k_gemm_f16_dma<1>, dim3((unsigned)grid1), dim3(256), 0, s, p);
+            else if (dbg1 == 2) hipLaunchKernelGGL(k_gemm_f16_dma<2>, dim3((unsigned)grid1), dim3(256), 0, s, p);
+            else if (dbg1 == 3) hipLaunchKernelGGL(k_gemm_f16_dma<3>, dim3((unsigned)grid1), dim3(256), 0, s, p);
+            else if (dbg1 == 4) hipLaunchKernelGGL(k_gemm_f16_dma<4>, dim3((unsigned)grid1), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL(k_gemm_f16_dma<0>, dim3((unsigned)grid1), dim3(256), 0, s, p);
+        }
+    }
     isc_timing_end(ISC_KERNEL_GEMM_F16, s);
     return isc_launch_status();
 }
 
 extern "C" int isc_layernorm(const float* x, int64_t rows, int D, int64_t ldx, const float* gamma, const float* beta,
-                             float eps, void* y, int y_dtype, int64_t ldy, void* stream) {
+                             float eps, void* y, int y_dtype, int64_t ldy, int y_packed, void* stream) {
     ISC_REQUIRE(x && gamma && beta && y && rows > 0 && D > 0 && eps >= 0.f);
     ISC_REQUIRE(y_dtype == ISC_F16 || y_dtype == ISC_F32);
     if (D % 4 != 0 || D > 2048) return ISC_ERR_UNSUPPORTED;
+    if (y_packed && (y_dtype != ISC_F16 || D % 64 != 0)) return ISC_ERR_UNSUPPORTED;
     if (ldx < D || ldy < D || ldx % 4 != 0 || ldy % 4 != 0) return ISC_ERR_ALIGNMENT;
     if (!isc_aligned(x, 16) || !isc_aligned(gamma, 16) || !isc_aligned(beta, 16) || !isc_aligned(y, 16))
         return ISC_ERR_ALIGNMENT;
@@ -438,30 +915,37 @@ extern "C" int isc_layernorm(const float* x, int64_t rows, int D, int64_t ldx, c
     const int nv = (D / 4 + 63) / 64;
     if (y_dtype == ISC_F32)
         launch_layernorm<true>(nv, dim3((unsigned)blocks), s, x, (long long)rows, D, (long long)ldx, gamma, beta, eps, y,
-                               (long long)ldy);
+                               (long long)ldy, 0);
     else
         launch_layernorm<false>(nv, dim3((unsigned)blocks), s, x, (long long)rows, D, (long long)ldx, gamma, beta, eps, y,
-                                (long long)ldy);
+                                (long long)ldy, y_packed ? 1 : 0);
     return isc_launch_status();
 }
 
-extern "C" int isc_attention_f16(const void* qkv, int B, int T, int heads, int head_dim, void* out, void* stream) {
+extern "C" int isc_attention_f16(const void* qkv, int B, int T, int heads, int head_dim, void* out, int packed,
+                                 void* stream) {
     ISC_REQUIRE(qkv && out && B > 0 && T > 0 && heads > 0);
     if (head_dim != 64 || T > ATT_TMAX) return ISC_ERR_UNSUPPORTED;
     if (!isc_aligned(qkv, 16) || !isc_aligned(out, 16)) return ISC_ERR_ALIGNMENT;
     if ((long long)B * heads > 0x7fffffffLL) return ISC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_attention_f16, dim3((unsigned)(B * heads)), dim3(ATT_THREADS), 0, isc_stream(stream),
-                       reinterpret_cast<const _Float16*>(qkv), T, heads, reinterpret_cast<_Float16*>(out));
+    if (packed)
+        hipLaunchKernelGGL(k_attention_f16<true>, dim3((unsigned)(B * heads)), dim3(ATT_THREADS), 0, isc_stream(stream),
+                           reinterpret_cast<const _Float16*>(qkv), T, heads, reinterpret_cast<_Float16*>(out));
+    else
+        hipLaunchKernelGGL(k_attention_f16<false>, dim3((unsigned)(B * heads)), dim3(ATT_THREADS), 0, isc_stream(stream),
+                           reinterpret_cast<const _Float16*>(qkv), T, heads, reinterpret_cast<_Float16*>(out));
     return isc_launch_status();
 }
 
-extern "C" int isc_patchify_f16(const float* x, int B, int C, int H, int W, int patch, void* patches, void* stream) {
+extern "C" int isc_patchify_f16(const float* x, int B, int C, int H, int W, int patch, void* patches, int packed,
+                                void* stream) {
     ISC_REQUIRE(x && patches && B > 0 && C > 0 && H > 0 && W > 0 && patch > 0);
     if (patch % 8 != 0 || H % patch != 0 || W % patch != 0) return ISC_ERR_UNSUPPORTED;
+    if (packed && (C * patch * patch) % 64 != 0) return ISC_ERR_UNSUPPORTED;
     if (!isc_aligned(x, 16) || !isc_aligned(patches, 16)) return ISC_ERR_ALIGNMENT;
     const size_t total8 = (size_t)B * C * H * (W / 8);
     hipLaunchKernelGGL(k_patchify_f16, dim3(grid_for(total8)), dim3(256), 0, isc_stream(stream), x, C, H, W, patch, total8,
-                       reinterpret_cast<_Float16*>(patches));
+                       reinterpret_cast<_Float16*>(patches), packed ? 1 : 0);
     return isc_launch_status();
 }
 

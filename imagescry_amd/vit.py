@@ -80,13 +80,41 @@ def gemm_flops(cfg: ViTConfig = VIT_B16) -> int:
     return 2 * (t - 1) * d * (3 * cfg.patch_size**2) + cfg.depth * per_layer
 
 
+def pack_rows(x: Tensor) -> Tensor:
+    """Row-major `[R, C]` (C % 64 == 0) -> the PACKED layout of include/imagescry_hip.h: rows in tiles of 256 (zero
+    padded), columns in K steps of 64, stored `[tile][K step][row][64]`; returned flat."""
+    r, c = x.shape
+    if c % 64:
+        raise ValueError(f"packed matrices need a multiple of 64 columns, got {c}")
+    tiles = (r + 255) // 256
+    padded = torch.zeros((tiles * 256, c), dtype=x.dtype, device=x.device)
+    padded[:r] = x
+    return padded.view(tiles, 256, c // 64, 64).permute(0, 2, 1, 3).contiguous().view(-1)
+
+
+def unpack_rows(flat: Tensor, rows: int, cols: int) -> Tensor:
+    """Inverse of `pack_rows`."""
+    tiles = (rows + 255) // 256
+    return flat.view(tiles, cols // 64, 256, 64).permute(0, 2, 1, 3).reshape(tiles * 256, cols)[:rows].contiguous()
+
+
+def packed_elems(rows: int, cols: int) -> int:
+    return (rows + 255) // 256 * 256 * cols
+
+
 @dataclass
 class Linear:
-    weight: Tensor  # fp16 [out, in]
+    weight: Tensor  # fp16, PACKED [out, in] (pack_rows of the torch.nn.Linear weight)
     bias: Tensor  # float32 [out]
+    out_features: int = 0
+    in_features: int = 0
+
+    def __post_init__(self) -> None:
+        if not self.out_features:
+            raise ValueError("Linear needs its logical shape")
 
     def to(self, device: torch.device) -> "Linear":
-        return Linear(self.weight.to(device), self.bias.to(device))
+        return Linear(self.weight.to(device), self.bias.to(device), self.out_features, self.in_features)
 
 
 @dataclass
@@ -126,7 +154,8 @@ class PreparedViT:
 
 
 def prepare(sd: dict[str, Tensor], cfg: ViTConfig = VIT_B16) -> PreparedViT:
-    """Cast GEMM weights to fp16 (round-to-nearest-even), keep biases / LayerNorm / tokens in float32."""
+    """Cast GEMM weights to fp16 (round-to-nearest-even) and store them in the packed layout the GEMM kernels stream; keep
+    biases / LayerNorm / tokens in float32."""
     d = cfg.dim
     if cfg.dim % 64 or cfg.mlp_dim % 64 or (3 * cfg.patch_size**2) % 64 or cfg.dim // cfg.heads != 64:
         raise ValueError("this build supports head size 64 and GEMM inner dimensions that are multiples of 64")
@@ -135,7 +164,8 @@ def prepare(sd: dict[str, Tensor], cfg: ViTConfig = VIT_B16) -> PreparedViT:
 
     def lin(name: str) -> Linear:
         w = sd[f"{name}.weight"]
-        return Linear(w.reshape(w.shape[0], -1).to(torch.float16).contiguous(), sd[f"{name}.bias"].float().contiguous())
+        w2 = w.reshape(w.shape[0], -1).to(torch.float16)
+        return Linear(pack_rows(w2), sd[f"{name}.bias"].float().contiguous(), w2.shape[0], w2.shape[1])
 
     def norm(name: str) -> Norm:
         return Norm(sd[f"{name}.weight"].float().contiguous(), sd[f"{name}.bias"].float().contiguous())
@@ -150,27 +180,32 @@ def prepare(sd: dict[str, Tensor], cfg: ViTConfig = VIT_B16) -> PreparedViT:
     return net
 
 
-def _gemm(a: Tensor, lin: Linear, out: Tensor, *, act: int = _lib.ISC_ACT_NONE, residual: Tensor | None = None,
+def _gemm(a: Tensor, m: int, lin: Linear, out: Tensor, *, act: int = _lib.ISC_ACT_NONE, residual: Tensor | None = None,
           stream: int = 0) -> Tensor:
-    m, k = a.shape
-    n = lin.weight.shape[0]
-    st = _lib.load().isc_gemm_f16(a.data_ptr(), m, k, lin.weight.data_ptr(), n, lin.bias.data_ptr(), _lib.ptr(residual),
-                                  act, out.data_ptr(), _lib.ISC_F16 if out.dtype == torch.float16 else _lib.ISC_F32, stream)
+    """`out = act(a . W^T + b) + residual`; `a` is a packed fp16 activation buffer of `m` rows, `out` either a packed
+    fp16 buffer (next GEMM operand) or a row-major float32 `[m, N]` tensor (residual stream)."""
+    f16 = out.dtype == torch.float16
+    flags = _lib.ISC_GEMM_A_PACKED | _lib.ISC_GEMM_W_PACKED | (_lib.ISC_GEMM_OUT_PACKED if f16 else 0)
+    st = _lib.load().isc_gemm_f16(a.data_ptr(), m, lin.in_features, lin.weight.data_ptr(), lin.out_features,
+                                  lin.bias.data_ptr(), _lib.ptr(residual), act, out.data_ptr(),
+                                  _lib.ISC_F16 if f16 else _lib.ISC_F32, flags, stream)
     _lib.check(st, "isc_gemm_f16")
     return out
 
 
-def _layernorm(x: Tensor, rows: int, ldx: int, nrm: Norm, eps: float, out: Tensor, stream: int) -> Tensor:
+def _layernorm_packed(x: Tensor, rows: int, nrm: Norm, eps: float, out: Tensor, stream: int) -> Tensor:
     d = nrm.weight.shape[0]
-    st = _lib.load().isc_layernorm(x.data_ptr(), rows, d, ldx, nrm.weight.data_ptr(), nrm.bias.data_ptr(), eps,
-                                   out.data_ptr(), _lib.ISC_F16 if out.dtype == torch.float16 else _lib.ISC_F32,
-                                   out.shape[-1], stream)
+    st = _lib.load().isc_layernorm(x.data_ptr(), rows, d, d, nrm.weight.data_ptr(), nrm.bias.data_ptr(), eps,
+                                   out.data_ptr(), _lib.ISC_F16, d, 1, stream)
     _lib.check(st, "isc_layernorm")
     return out
 
 
 def forward_cls(net: PreparedViT, x: Tensor) -> Tensor:
-    """float32 `[B, 3, S, S]` (already preprocessed) on a HIP device -> float32 `[B, D]` class-token features."""
+    """float32 `[B, 3, S, S]` (already preprocessed) on a HIP device -> float32 `[B, D]` class-token features.
+
+    Every fp16 activation (patches, LayerNorm outputs, qkv, attention output, MLP hidden) lives in the packed layout;
+    the float32 residual stream is row-major."""
     cfg = net.cfg
     b = x.shape[0]
     t, d = cfg.tokens, cfg.dim
@@ -179,34 +214,39 @@ def forward_cls(net: PreparedViT, x: Tensor) -> Tensor:
     lib = _lib.load()
     stream = _lib.stream_handle(dev)
     f16, f32 = torch.float16, torch.float32
+    kdim = 3 * cfg.patch_size**2
 
-    patches = torch.empty((b * (t - 1), 3 * cfg.patch_size**2), dtype=f16, device=dev)
+    def packed(rows: int, cols: int) -> Tensor:
+        # rows past `rows` in the last tile are never read into a result that is kept; they only have to be finite
+        # enough not to matter, and every consumer masks them, so the buffer is left uninitialised
+        return torch.empty(packed_elems(rows, cols), dtype=f16, device=dev)
+
+    patches = packed(b * (t - 1), kdim)
     _lib.check(lib.isc_patchify_f16(x.data_ptr(), b, 3, cfg.image_size, cfg.image_size, cfg.patch_size,
-                                    patches.data_ptr(), stream), "isc_patchify_f16")
+                                    patches.data_ptr(), 1, stream), "isc_patchify_f16")
     pe = torch.empty((b * (t - 1), d), dtype=f32, device=dev)
-    _gemm(patches, net.patch, pe, stream=stream)
+    _gemm(patches, b * (t - 1), net.patch, pe, stream=stream)
     del patches
     xa = torch.empty((m, d), dtype=f32, device=dev)  # residual stream (ping)
     xb = torch.empty((m, d), dtype=f32, device=dev)  # residual stream (pong)
     _lib.check(lib.isc_vit_assemble(pe.data_ptr(), net.cls_token.data_ptr(), net.pos_embed.data_ptr(), b, t, d,
                                     xa.data_ptr(), stream), "isc_vit_assemble")
     del pe
-    hbuf = torch.empty((m, d), dtype=f16, device=dev)
-    qkv = torch.empty((m, 3 * d), dtype=f16, device=dev)
-    att = torch.empty((m, d), dtype=f16, device=dev)
-    mlp = torch.empty((m, cfg.mlp_dim), dtype=f16, device=dev)
+    hbuf, qkv, att, mlp = packed(m, d), packed(m, 3 * d), packed(m, d), packed(m, cfg.mlp_dim)
     for blk in net.blocks:
-        _layernorm(xa, m, d, blk.norm1, cfg.ln_eps, hbuf, stream)
-        _gemm(hbuf, blk.qkv, qkv, stream=stream)
-        _lib.check(lib.isc_attention_f16(qkv.data_ptr(), b, t, cfg.heads, d // cfg.heads, att.data_ptr(), stream),
+        _layernorm_packed(xa, m, blk.norm1, cfg.ln_eps, hbuf, stream)
+        _gemm(hbuf, m, blk.qkv, qkv, stream=stream)
+        _lib.check(lib.isc_attention_f16(qkv.data_ptr(), b, t, cfg.heads, d // cfg.heads, att.data_ptr(), 1, stream),
                    "isc_attention_f16")
-        _gemm(att, blk.proj, xb, residual=xa, stream=stream)
-        _layernorm(xb, m, d, blk.norm2, cfg.ln_eps, hbuf, stream)
-        _gemm(hbuf, blk.fc1, mlp, act=_lib.ISC_ACT_GELU, stream=stream)
-        _gemm(mlp, blk.fc2, xa, residual=xb, stream=stream)
+        _gemm(att, m, blk.proj, xb, residual=xa, stream=stream)
+        _layernorm_packed(xb, m, blk.norm2, cfg.ln_eps, hbuf, stream)
+        _gemm(hbuf, m, blk.fc1, mlp, act=_lib.ISC_ACT_GELU, stream=stream)
+        _gemm(mlp, m, blk.fc2, xa, residual=xb, stream=stream)
     out = torch.empty((b, d), dtype=f32, device=dev)
-    _layernorm(xa, b, t * d, net.norm, cfg.ln_eps, out, stream)  # class-token rows only (row stride T * D)
+    st = lib.isc_layernorm(xa.data_ptr(), b, d, t * d, net.norm.weight.data_ptr(), net.norm.bias.data_ptr(), cfg.ln_eps,
+                           out.data_ptr(), _lib.ISC_F32, d, 0, stream)  # class-token rows only (row stride T * D)
+    _lib.check(st, "isc_layernorm")
     return out
 
 
-__all__ = ["VIT_B16", "ViTConfig", "forward_cls", "gemm_flops", "make_state_dict", "prepare"]
+__all__ = ["VIT_B16", "ViTConfig", "forward_cls", "gemm_flops", "make_state_dict", "pack_rows", "prepare", "unpack_rows"]

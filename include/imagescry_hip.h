@@ -175,26 +175,38 @@ int isc_global_avgpool_nhwc(const float* x, int B, int H, int W, int C, float* y
  * The reference's encoder is any `EmbeddingModule.forward` (models/embedding.py:91-104); these are the blocks a
  * ViT forward is composed of (torch.nn.Linear / LayerNorm / scaled_dot_product_attention in a torch build). */
 
-/* out[M,N] = act(a[M,K] . w[N,K]^T + bias[N]) + residual[M,N].   a, w fp16 row-major (w in torch.nn.Linear layout);
- * bias, residual float32 (either may be NULL); act ISC_ACT_NONE or ISC_ACT_GELU; out fp16 or float32 (`out_dtype`).
- * K % 64 == 0, N % 4 == 0, all pointers 16-byte aligned. */
+/* PACKED fp16 matrix layout (flags below): the embedding bank's layout (isc_bank_pack) applied to GEMM operands --
+ * rows in tiles of 256, columns in K steps of 64 halves, stored [tile][K step][row][64 halves]; a matrix of R rows
+ * and C columns (C % 64 == 0) occupies ceil(R / 256) * 256 * C halves.  element (r, c) sits at
+ * (((r / 256) * (C / 64) + c / 64) * 256 + r % 256) * 64 + c % 64.  One K step of one tile is 32 KiB of contiguous
+ * memory, so the operand stream of a GEMM uses every L2 channel (row-major K steps are a whole row apart). */
+#define ISC_GEMM_A_PACKED 1   /* `a` is packed */
+#define ISC_GEMM_W_PACKED 2   /* `w` is packed */
+#define ISC_GEMM_OUT_PACKED 4 /* `out` (fp16 only, N % 64 == 0) is written packed */
+#define ISC_GEMM_TILE_256 8   /* use the 256 x 256-tile kernel (one wave per SIMD, LDS-DMA rings); needs K >= 192,
+                                 act == ISC_ACT_NONE and operands below 4 GiB, else ISC_ERR_UNSUPPORTED */
+
+/* out[M,N] = act(a[M,K] . w[N,K]^T + bias[N]) + residual[M,N].   a, w fp16, row-major (w in torch.nn.Linear layout)
+ * or packed per `flags`; bias, residual float32 row-major (either may be NULL); act ISC_ACT_NONE or ISC_ACT_GELU;
+ * out fp16 or float32 (`out_dtype`).  K % 64 == 0, N % 4 == 0, all pointers 16-byte aligned. */
 int isc_gemm_f16(const void* a, int64_t M, int K, const void* w, int N, const float* bias, const float* residual,
-                 int act, void* out, int out_dtype, void* stream);
+                 int act, void* out, int out_dtype, int flags, void* stream);
 
 /* LayerNorm over the last axis (biased variance, float32 statistics): x float32 [rows, D] with row stride ldx,
- * y fp16 or float32 (`y_dtype`) with row stride ldy (strides in elements, multiples of 4).  D % 4 == 0, D <= 2048. */
+ * y fp16 or float32 (`y_dtype`) with row stride ldy (strides in elements, multiples of 4), or -- y_packed != 0, fp16,
+ * D % 64 == 0 -- in the packed layout.  D % 4 == 0, D <= 2048. */
 int isc_layernorm(const float* x, int64_t rows, int D, int64_t ldx, const float* gamma, const float* beta, float eps,
-                  void* y, int y_dtype, int64_t ldy, void* stream);
+                  void* y, int y_dtype, int64_t ldy, int y_packed, void* stream);
 
-/* softmax(q k^T / sqrt(head_dim)) v per (image, head).  qkv fp16 [B, T, 3 * heads * head_dim] laid out as the output
- * of one fused Linear whose weight rows are [query; key; value], each head-major; out fp16 [B, T, heads * head_dim].
- * head_dim == 64, T <= 224. */
-int isc_attention_f16(const void* qkv, int B, int T, int heads, int head_dim, void* out, void* stream);
+/* softmax(q k^T / sqrt(head_dim)) v per (image, head).  qkv fp16 [B * T, 3 * heads * head_dim] laid out as the output
+ * of one fused Linear whose weight rows are [query; key; value], each head-major; out fp16 [B * T, heads * head_dim];
+ * both row-major (packed == 0) or both packed.  head_dim == 64, T <= 224. */
+int isc_attention_f16(const void* qkv, int B, int T, int heads, int head_dim, void* out, int packed, void* stream);
 
-/* non-overlapping patches of an NCHW float32 image batch as fp16 GEMM rows:
+/* non-overlapping patches of an NCHW float32 image batch as fp16 GEMM rows (row-major or packed):
  * patches[(b, ph, pw)][c * P * P + r * P + s] = x[b][c][ph * P + r][pw * P + s]   (torch Conv2d(kernel=stride=P) weight
  * order).  P % 8 == 0, H % P == 0, W % P == 0. */
-int isc_patchify_f16(const float* x, int B, int C, int H, int W, int patch, void* patches, void* stream);
+int isc_patchify_f16(const float* x, int B, int C, int H, int W, int patch, void* patches, int packed, void* stream);
 
 /* tokens[b][0] = cls + pos[0]; tokens[b][t] = patch_embed[b * (T - 1) + t - 1] + pos[t]; all float32, D % 4 == 0. */
 int isc_vit_assemble(const float* patch_embed, const float* cls_token, const float* pos_embed, int B, int T, int D,

@@ -1,7 +1,7 @@
 """Bring-up timing of EmbeddingBank.search (not the contract bench; see bench.py)."""
 import os, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from imagescry_amd import EmbeddingBank
 
 dev = torch.device("cuda:0")

@@ -22,6 +22,7 @@ def _gen(seed: int) -> torch.Generator:
     return torch.Generator().manual_seed(seed)
 
 
+@pytest.mark.parametrize("layout", ["rowmajor", "packed", "packed-tile256", "rowmajor-tile256"])
 @pytest.mark.parametrize(
     "m,k,n,act,res,out_f32",
     [
@@ -31,10 +32,21 @@ def _gen(seed: int) -> torch.Generator:
         (257, 3072, 768, "none", True, True),  # fc2, long reduction
         (1, 64, 4, "none", False, True),  # smallest legal problem: one row, four features
         (129, 128, 132, "gelu", True, False),  # ragged in both tile directions
+        (2100, 768, 768, "none", True, True),  # several tiles, ragged last one
+        (2304, 3072, 772, "none", True, True),  # 48 K steps, ragged feature tile
+        (2049, 192, 2304, "none", False, False),  # 3 K steps (the minimum of the 256-tile kernel), fp16 output
     ],
 )
-def test_gemm_f16(device, m, k, n, act, res, out_f32):
+def test_gemm_f16(device, m, k, n, act, res, out_f32, layout):
     from imagescry_amd import _lib
+    from imagescry_amd.vit import pack_rows, packed_elems, unpack_rows
+
+    pk = layout.startswith("packed")
+    tile256 = layout.endswith("tile256")
+    if pk and n % 64 and not out_f32:
+        pytest.skip("a packed fp16 output needs N % 64 == 0")
+    if tile256 and (act != "none" or k < 192):
+        pytest.skip("the 256-tile kernel has no activation epilogue and needs three K steps")
 
     g = _gen(m + k + n)
     a = (torch.randn(m, k, generator=g)).half()
@@ -46,14 +58,21 @@ def test_gemm_f16(device, m, k, n, act, res, out_f32):
         want = F.gelu(want)
     if res:
         want = want + r.double()
-    ad, wd, bd = a.to(device), w.to(device), bias.to(device)
+    ad, wd, bd = (pack_rows(a) if pk else a).to(device), (pack_rows(w) if pk else w).to(device), bias.to(device)
     rd = r.to(device) if res else None
-    out = torch.full((m, n), float("nan"), dtype=torch.float32 if out_f32 else torch.float16, device=device)
+    flags = 0
+    if pk:
+        flags = _lib.ISC_GEMM_A_PACKED | _lib.ISC_GEMM_W_PACKED | (0 if out_f32 else _lib.ISC_GEMM_OUT_PACKED)
+    if tile256:
+        flags |= _lib.ISC_GEMM_TILE_256
+    n_out = packed_elems(m, n) if pk and not out_f32 else m * n
+    out = torch.full((n_out,), float("nan"), dtype=torch.float32 if out_f32 else torch.float16, device=device)
     st = _lib.load().isc_gemm_f16(ad.data_ptr(), m, k, wd.data_ptr(), n, bd.data_ptr(), _lib.ptr(rd),
                                   _lib.ISC_ACT_GELU if act == "gelu" else _lib.ISC_ACT_NONE, out.data_ptr(),
-                                  _lib.ISC_F32 if out_f32 else _lib.ISC_F16, _lib.stream_handle(device))
+                                  _lib.ISC_F32 if out_f32 else _lib.ISC_F16, flags, _lib.stream_handle(device))
     _lib.check(st, "isc_gemm_f16")
-    got = out.double().cpu()
+    out = unpack_rows(out.cpu(), m, n) if pk and not out_f32 else out.cpu().view(m, n)
+    got = out.double()
     if out_f32:
         torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
     else:
@@ -68,29 +87,39 @@ def test_gemm_f16_rejects_bad_arguments(device):
     w = torch.zeros(8, 96, dtype=torch.float16, device=device)
     out = torch.zeros(8, 8, dtype=torch.float32, device=device)
     s = _lib.stream_handle(device)
-    assert lib.isc_gemm_f16(a.data_ptr(), 8, 96, w.data_ptr(), 8, None, None, 0, out.data_ptr(), _lib.ISC_F32, s) == \
+    assert lib.isc_gemm_f16(a.data_ptr(), 8, 96, w.data_ptr(), 8, None, None, 0, out.data_ptr(), _lib.ISC_F32, 0, s) == \
         _lib.ISC_ERR_UNSUPPORTED  # K % 64
-    assert lib.isc_gemm_f16(a.data_ptr(), 8, 64, w.data_ptr(), 6, None, None, 0, out.data_ptr(), _lib.ISC_F32, s) == \
+    assert lib.isc_gemm_f16(a.data_ptr(), 8, 64, w.data_ptr(), 6, None, None, 0, out.data_ptr(), _lib.ISC_F32, 0, s) == \
         _lib.ISC_ERR_UNSUPPORTED  # N % 4
     assert lib.isc_gemm_f16(a.data_ptr(), 8, 64, w.data_ptr(), 8, None, None, _lib.ISC_ACT_RELU, out.data_ptr(),
-                            _lib.ISC_F32, s) == _lib.ISC_ERR_INVALID_ARG
-    assert lib.isc_gemm_f16(None, 8, 64, w.data_ptr(), 8, None, None, 0, out.data_ptr(), _lib.ISC_F32, s) == \
+                            _lib.ISC_F32, 0, s) == _lib.ISC_ERR_INVALID_ARG
+    assert lib.isc_gemm_f16(None, 8, 64, w.data_ptr(), 8, None, None, 0, out.data_ptr(), _lib.ISC_F32, 0, s) == \
         _lib.ISC_ERR_INVALID_ARG
+    assert lib.isc_gemm_f16(a.data_ptr(), 8, 64, w.data_ptr(), 8, None, None, 0, out.data_ptr(), _lib.ISC_F32,
+                            _lib.ISC_GEMM_OUT_PACKED, s) == _lib.ISC_ERR_UNSUPPORTED  # packed output is fp16 only
+    assert lib.isc_gemm_f16(a.data_ptr(), 8, 64, w.data_ptr(), 8, None, None, 0, out.data_ptr(), _lib.ISC_F32, 16, s) == \
+        _lib.ISC_ERR_INVALID_ARG  # unknown flag
+    assert lib.isc_gemm_f16(a.data_ptr(), 8, 64, w.data_ptr(), 8, None, None, 0, out.data_ptr(), _lib.ISC_F32,
+                            _lib.ISC_GEMM_TILE_256, s) == _lib.ISC_ERR_UNSUPPORTED  # one K step only
 
 
-@pytest.mark.parametrize("rows,d,out_f32", [(37, 768, False), (5, 768, True), (9, 2048, False), (3, 4, True)])
-def test_layernorm(device, rows, d, out_f32):
+@pytest.mark.parametrize("rows,d,out_f32,pk", [(37, 768, False, False), (5, 768, True, False), (9, 2048, False, False),
+                                                (3, 4, True, False), (300, 768, False, True)])
+def test_layernorm(device, rows, d, out_f32, pk):
     from imagescry_amd import _lib
+    from imagescry_amd.vit import packed_elems, unpack_rows
 
     g = _gen(rows * d)
     x = torch.randn(rows, d, generator=g) * 3 + 1.5
     gamma, beta = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g)
     want = F.layer_norm(x, (d,), gamma, beta, 1e-6)
     xd, gd, bd = x.to(device), gamma.to(device), beta.to(device)
-    out = torch.empty((rows, d), dtype=torch.float32 if out_f32 else torch.float16, device=device)
+    out = torch.empty(packed_elems(rows, d) if pk else rows * d, dtype=torch.float32 if out_f32 else torch.float16,
+                      device=device)
     st = _lib.load().isc_layernorm(xd.data_ptr(), rows, d, d, gd.data_ptr(), bd.data_ptr(), 1e-6, out.data_ptr(),
-                                   _lib.ISC_F32 if out_f32 else _lib.ISC_F16, d, _lib.stream_handle(device))
+                                   _lib.ISC_F32 if out_f32 else _lib.ISC_F16, d, int(pk), _lib.stream_handle(device))
     _lib.check(st, "isc_layernorm")
+    out = unpack_rows(out, rows, d) if pk else out.view(rows, d)
     if out_f32:
         torch.testing.assert_close(out.cpu(), want, rtol=1e-5, atol=1e-5)
     else:
@@ -108,14 +137,16 @@ def test_layernorm_strided_rows(device):
     xd, gd, bd = x.to(device), gamma.to(device), beta.to(device)
     out = torch.empty((6, 768), dtype=torch.float32, device=device)
     st = _lib.load().isc_layernorm(xd.data_ptr(), 6, 768, 5 * 768, gd.data_ptr(), bd.data_ptr(), 1e-6, out.data_ptr(),
-                                   _lib.ISC_F32, 768, _lib.stream_handle(device))
+                                   _lib.ISC_F32, 768, 0, _lib.stream_handle(device))
     _lib.check(st, "isc_layernorm")
     torch.testing.assert_close(out.cpu(), want, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("pk", [False, True])
 @pytest.mark.parametrize("b,t,heads", [(2, 197, 12), (3, 17, 2), (1, 224, 1), (2, 1, 3), (1, 16, 4), (1, 50, 12)])
-def test_attention(device, b, t, heads):
+def test_attention(device, b, t, heads, pk):
     from imagescry_amd import _lib
+    from imagescry_amd.vit import pack_rows, packed_elems, unpack_rows
 
     d = heads * 64
     g = _gen(b * t + heads)
@@ -123,10 +154,11 @@ def test_attention(device, b, t, heads):
     q, k, v = (z.reshape(b, t, heads, 64).transpose(1, 2).double() for z in qkv.split(d, dim=-1))
     att = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1)
     want = (att @ v).transpose(1, 2).reshape(b, t, d)
-    qd = qkv.to(device)
-    out = torch.full((b, t, d), float("nan"), dtype=torch.float16, device=device)
-    st = _lib.load().isc_attention_f16(qd.data_ptr(), b, t, heads, 64, out.data_ptr(), _lib.stream_handle(device))
+    qd = (pack_rows(qkv.reshape(b * t, 3 * d)) if pk else qkv).to(device)
+    out = torch.full((packed_elems(b * t, d) if pk else b * t * d,), float("nan"), dtype=torch.float16, device=device)
+    st = _lib.load().isc_attention_f16(qd.data_ptr(), b, t, heads, 64, out.data_ptr(), int(pk), _lib.stream_handle(device))
     _lib.check(st, "isc_attention_f16")
+    out = (unpack_rows(out, b * t, d) if pk else out).view(b, t, d)
     # probabilities are rounded to fp16 before the second product and the output is fp16
     torch.testing.assert_close(out.double().cpu(), want, rtol=4e-3, atol=2e-3)
 
@@ -138,8 +170,8 @@ def test_attention_limits(device):
     x = torch.zeros(1, 225, 192, dtype=torch.float16, device=device)
     o = torch.zeros(1, 225, 64, dtype=torch.float16, device=device)
     s = _lib.stream_handle(device)
-    assert lib.isc_attention_f16(x.data_ptr(), 1, 225, 1, 64, o.data_ptr(), s) == _lib.ISC_ERR_UNSUPPORTED
-    assert lib.isc_attention_f16(x.data_ptr(), 1, 100, 1, 32, o.data_ptr(), s) == _lib.ISC_ERR_UNSUPPORTED
+    assert lib.isc_attention_f16(x.data_ptr(), 1, 225, 1, 64, o.data_ptr(), 0, s) == _lib.ISC_ERR_UNSUPPORTED
+    assert lib.isc_attention_f16(x.data_ptr(), 1, 100, 1, 32, o.data_ptr(), 0, s) == _lib.ISC_ERR_UNSUPPORTED
 
 
 def test_patchify_and_assemble(device):
@@ -153,8 +185,13 @@ def test_patchify_and_assemble(device):
     want = F.unfold(x, kernel_size=p, stride=p).transpose(1, 2).reshape(b * (hh // p) * (ww // p), c * p * p).half()
     xd = x.to(device)
     out = torch.empty(want.shape, dtype=torch.float16, device=device)
-    _lib.check(lib.isc_patchify_f16(xd.data_ptr(), b, c, hh, ww, p, out.data_ptr(), s), "isc_patchify_f16")
+    _lib.check(lib.isc_patchify_f16(xd.data_ptr(), b, c, hh, ww, p, out.data_ptr(), 0, s), "isc_patchify_f16")
     assert torch.equal(out.cpu(), want)
+    from imagescry_amd.vit import packed_elems, unpack_rows
+
+    outp = torch.zeros(packed_elems(*want.shape), dtype=torch.float16, device=device)
+    _lib.check(lib.isc_patchify_f16(xd.data_ptr(), b, c, hh, ww, p, outp.data_ptr(), 1, s), "isc_patchify_f16")
+    assert torch.equal(unpack_rows(outp, *want.shape).cpu(), want)
 
     t, d = 13, 768
     pe = torch.randn(b * (t - 1), d, generator=g)

@@ -29,8 +29,12 @@ def test_vit_state_dict_shapes_and_parameter_count():
     assert sum(v.numel() for v in sd.values()) == 85_798_656  # ViT-B/16 without pooler / classifier head
     assert vit.VIT_B16.tokens == 197
     net = vit.prepare(sd)
-    assert net.blocks[0].qkv.weight.dtype == torch.float16 and net.blocks[0].qkv.weight.shape == (2304, 768)
-    assert net.patch.weight.shape == (768, 768)
+    qkv = net.blocks[0].qkv
+    assert qkv.weight.dtype == torch.float16 and (qkv.out_features, qkv.in_features) == (2304, 768)
+    assert torch.equal(vit.unpack_rows(qkv.weight, 2304, 768), sd["blocks.0.attn.qkv.weight"].half())  # packed storage
+    assert (net.patch.out_features, net.patch.in_features) == (768, 768)
+    x = torch.arange(300 * 128, dtype=torch.float32).reshape(300, 128)
+    assert torch.equal(vit.unpack_rows(vit.pack_rows(x), 300, 128), x) and vit.pack_rows(x).numel() == 512 * 128
     with pytest.raises(ValueError):
         vit.prepare(sd, vit.ViTConfig(image_size=256))
 
