@@ -2,7 +2,8 @@
 // isc_attention_f16, isc_patchify_f16, isc_vit_assemble).  Used by the ViT-B/16 embedder (BASELINE.json configs[4]).
 //
 // Numerics: every product is fp16 x fp16 accumulated in float32 (v_mfma_f32_16x16x32_f16); the residual stream,
-// LayerNorm statistics, softmax statistics, bias and GELU are float32.  Only GEMM operands are rounded to fp16.
+// LayerNorm statistics, softmax statistics, bias and GELU (erf form, erf from a 1.5e-7 polynomial) are float32.  Only
+// GEMM operands are rounded to fp16.
 #include <stdlib.h>
 
 #include "isc_common.h"
@@ -21,7 +22,18 @@ __device__ __forceinline__ void g2_dma16(const unsigned char* gsrc, unsigned cha
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+// GELU with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, below float32 rounding of the product for |v| < 4):
+// a third of the instructions of erff(), which matters where 16 values per lane pass through it in an epilogue.
+__device__ __forceinline__ float gelu_fast(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, x, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = 1.f - poly * t * __expf(-x * x);  // erf(|v| / sqrt 2)
+    return 0.5f * v + 0.5f * fabsf(v) * e;             // 0.5 v (1 + sign(v) erf(|v| / sqrt 2))
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // out[m][n] = act( sum_k a[m][k] * w[n][k] + bias[n] ) + residual[m][n]
@@ -44,8 +56,10 @@ struct GemmParams {
 
 // The PACKED fp16 matrix layout (the embedding bank's layout, bank_layout.h): rows in tiles of 256, columns in K steps of
 // 64 halves, stored [tile][K step][row][64 halves].  The 256 x 128 B block one K step of one tile needs is 32 KiB of
-// contiguous memory, so a GEMM's operand stream uses every L2 channel; with row-major operands the 128-byte pieces of a
-// K step are a whole row (1.5 - 6 KiB) apart and land on 2 - 8 of the 16 channels.
+// contiguous memory and every 1 KiB LDS-DMA instruction reads one contiguous KiB; a head's 64 q / k / v values of a token
+// are exactly one 128-byte segment, consecutive tokens 128 bytes apart, which is what the attention kernel reads.
+// (Measured on the ViT-B shapes: the GEMMs run at the same speed from row-major operands -- their cost is the
+// epilogue traffic and the staging volume, not the access pattern.)
 __host__ __device__ __forceinline__ size_t pk_offset(long long row, int col, int cols) {
     return (((size_t)(row >> 8) * (size_t)(cols >> 6) + (size_t)(col >> 6)) * 256 + (size_t)(row & 255)) * 64 + (size_t)(col & 63);
 }
@@ -81,135 +95,13 @@ __device__ __forceinline__ bool gemm_tile(const GemmParams& p, long long& m0, in
     return true;
 }
 
-template <int TN, int TM>
-__global__ __launch_bounds__(256, 2) void k_gemm_f16(const GemmParams p) {
-    constexpr int WN = TN / 64;
-    constexpr int NA = TN * 8 / 256;
-    constexpr int NB = TM * 8 / 256;
-    constexpr int A_BYTES = TN * 128;
-    constexpr int B_BYTES = TM * 128;
-    constexpr int BUF_BYTES = A_BYTES + B_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF_BYTES];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wn = wave % WN;
-    const int wm = wave / WN;
-    long long m0;
-    int n0;
-    if (!gemm_tile<TM, TN>(p, m0, n0)) return;
-
-    const int srow = tid >> 3;
-    const int lchunk = (tid & 7) ^ ((srow >> 1) & 7);
-    const unsigned char* a_ptr[NA];
-    const unsigned char* b_ptr[NB];
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-        a_ptr[i] = reinterpret_cast<const unsigned char*>(p.w) +
-                   operand_row_bytes(min(n0 + srow + 32 * i, p.N - 1), p.K, p.w_packed) + lchunk * 16;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        long long m = m0 + srow + 32 * i;
-        if (m > p.M - 1) m = p.M - 1;
-        b_ptr[i] = reinterpret_cast<const unsigned char*>(p.a) + operand_row_bytes(m, p.K, p.a_packed) + lchunk * 16;
-    }
-    const int a_kstride = operand_kstride(p.w_packed), b_kstride = operand_kstride(p.a_packed);
-
-    const int frow = lane & 15;
-    const int fg = lane >> 4;
-    const int fsw = (lane >> 1) & 7;
-    int foff[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) foff[kk] = frow * 128 + (((kk * 4 + fg) ^ fsw) << 4);
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int n = n0 + wn * 64 + mi * 16 + fg * 4;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) v = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = v;
-    }
-
-    u32x4 sa[NA], sb[NB];
-    auto load_step = [&](int ks) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) sa[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + (size_t)ks * a_kstride);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) sb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + (size_t)ks * b_kstride);
-    };
-    auto store_step = [&](int buf) {
-        unsigned char* a = lds + buf * BUF_BYTES + tid * 16;
-        unsigned char* b = a + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(a + 4096 * i) = sa[i];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(b + 4096 * i) = sb[i];
-    };
-
-    load_step(0);
-    store_step(0);
-    __syncthreads();
-
-    for (int ks = 0; ks < p.ksteps; ++ks) {
-        const int buf = ks & 1;
-        const bool more = ks + 1 < p.ksteps;
-        if (more) load_step(ks + 1);
-        const unsigned char* a_img = lds + buf * BUF_BYTES + wn * 64 * 128;
-        const unsigned char* b_img = lds + buf * BUF_BYTES + A_BYTES + wm * 64 * 128;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            u32x4 a[4], b[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const u32x4*>(a_img + mi * 2048 + foff[kk]);
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const u32x4*>(b_img + ni * 2048 + foff[kk]);
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a[mi]),
-                                                                         __builtin_bit_cast(half8, b[ni]), acc[mi][ni],
-                                                                         0, 0, 0);
-        }
-        if (more) store_step(buf ^ 1);
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const long long m = m0 + wm * 64 + ni * 16 + frow;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int n = n0 + wn * 64 + mi * 16 + fg * 4;
-            if (n >= p.N) continue;  // N % 4 == 0
-            f32x4 v = acc[mi][ni];
-            if (p.act == ISC_ACT_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            }
-            const size_t o = (size_t)m * p.N + n;
-            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
-            if (p.out_f32) {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
-            } else {
-                half4 h = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(p.out) + (p.out_packed ? pk_offset(m, n, p.N) : o)) = h;
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// The same 128 x 128 tile staged by LDS-DMA instead of registers.  A `ds_write_b128` costs 13 LDS cycles per wave
-// instruction (the VGPR -> LDS transfer, MI355X_MICROARCH.md "LDS"), so the register-staged kernel above spends about as
-// long storing a K step into LDS as the matrix cores need for it; `global_load_lds_dwordx4` writes the LDS directly.
-// Two stages of 32 KiB per workgroup (two workgroups per CU): iteration s issues the DMA of step s + 1, computes step
-// s from fragments read with inline-asm `ds_read_b128` (a C++ LDS load would make hipcc drain the DMA first), then
-// vmcnt(0) + one barrier.  The second workgroup on the CU covers the wait.
+// 128 x 128 tile, four waves of 64 x 64, two workgroups per CU, operands staged by LDS-DMA
+// (`global_load_lds_dwordx4` writes the LDS directly; a register-staged `ds_write_b128` costs 13 LDS cycles per wave
+// instruction -- MI355X_MICROARCH.md "LDS" -- about what the matrix cores need for the same K step).
+// Two stages of 32 KiB per workgroup: iteration s issues the DMA of step s + 1, computes step s from fragments read
+// with inline-asm `ds_read_b128` (a C++ LDS load would make hipcc drain the DMA first), then vmcnt(0) + one barrier;
+// the second workgroup on the CU covers the wait and the other's epilogue.
 #define G1_DS_READ(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_))
 
 // DBG (ISC_GEMM_DEBUG, bring-up only, wrong results): 1 = no DMA after the prologue, 2 = no fragment reads, 3 = no MFMAs,
@@ -235,10 +127,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_dma(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = wave * 32 + j * 8 + (lane >> 3);
-        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        const int lcx = (lane & 7) ^ ((r >> 1) & 7);
+        // weight rows use their own swizzle, ((r >> 4) & 3) << 1 | (r >> 1) & 1: conflict-free for the PERMUTED
+        // fragment rows read below (rows 16 g + 4 mi + q, not 16 mi + r)
+        const int lcw = (lane & 7) ^ ((((r >> 4) & 3) << 1) | ((r >> 1) & 1));
         const long long xr = m0 + r < p.M ? m0 + r : p.M - 1;
-        wsrc[j] = reinterpret_cast<const unsigned char*>(p.w) + operand_row_bytes(min(n0 + r, p.N - 1), p.K, p.w_packed) + lc * 16;
-        xsrc[j] = reinterpret_cast<const unsigned char*>(p.a) + operand_row_bytes(xr, p.K, p.a_packed) + lc * 16;
+        wsrc[j] = reinterpret_cast<const unsigned char*>(p.w) + operand_row_bytes(min(n0 + r, p.N - 1), p.K, p.w_packed) + lcw * 16;
+        xsrc[j] = reinterpret_cast<const unsigned char*>(p.a) + operand_row_bytes(xr, p.K, p.a_packed) + lcx * 16;
     }
     const int w_kstride = operand_kstride(p.w_packed), x_kstride = operand_kstride(p.a_packed);
     unsigned char* dma_dst = lds + wave * 4096;  // + stage, + 16 KiB for the activation half, + 1024 j
@@ -255,8 +150,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_dma(const GemmParams p) {
     const int fg = lane >> 4;
     const int fsw = (lane >> 1) & 7;
     const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const unsigned a_frag0 = lds_addr + wn * 8192 + frow * 128 + (((0 + fg) ^ fsw) << 4);
-    const unsigned a_frag1 = lds_addr + wn * 8192 + frow * 128 + (((4 + fg) ^ fsw) << 4);
+    // Weight fragment rows are PERMUTED: MFMA row r of block mi is feature 16 (r >> 2) + 4 mi + (r & 3) of the wave's 64.
+    // The result registers of a lane (rows 4 fg + q of every block) are then features 16 fg + 4 mi + q: SIXTEEN
+    // consecutive features of one token instead of four groups of four, so the epilogue stores 32 (fp16) or 64 (f32)
+    // contiguous bytes per lane and a token's four lanes fill whole 128-byte lines.
+    const int arow = 16 * (frow >> 2) + (frow & 3);  // + 4 mi
+    const int asw = ((frow >> 2) << 1) | ((frow >> 1) & 1);
+    const unsigned a_frag0 = lds_addr + wn * 8192 + arow * 128 + (((0 + fg) ^ asw) << 4);
+    const unsigned a_frag1 = lds_addr + wn * 8192 + arow * 128 + (((4 + fg) ^ asw) << 4);
     const unsigned b_frag0 = lds_addr + 16384 + wm * 8192 + frow * 128 + (((0 + fg) ^ fsw) << 4);
     const unsigned b_frag1 = lds_addr + 16384 + wm * 8192 + frow * 128 + (((4 + fg) ^ fsw) << 4);
 
@@ -280,17 +181,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_dma(const GemmParams p) {
             for (int i = 0; i < 4; ++i) a0[i] = b0[i] = a1[i] = b1[i] = u32x4{(unsigned)s, 1u, (unsigned)lane, 3u};
         } else {
         G1_DS_READ(a0[0], aa0, 0);
-        G1_DS_READ(a0[1], aa0, 2048);
-        G1_DS_READ(a0[2], aa0, 4096);
-        G1_DS_READ(a0[3], aa0, 6144);
+        G1_DS_READ(a0[1], aa0, 512);
+        G1_DS_READ(a0[2], aa0, 1024);
+        G1_DS_READ(a0[3], aa0, 1536);
         G1_DS_READ(b0[0], bb0, 0);
         G1_DS_READ(b0[1], bb0, 2048);
         G1_DS_READ(b0[2], bb0, 4096);
         G1_DS_READ(b0[3], bb0, 6144);
         G1_DS_READ(a1[0], aa1, 0);
-        G1_DS_READ(a1[1], aa1, 2048);
-        G1_DS_READ(a1[2], aa1, 4096);
-        G1_DS_READ(a1[3], aa1, 6144);
+        G1_DS_READ(a1[1], aa1, 512);
+        G1_DS_READ(a1[2], aa1, 1024);
+        G1_DS_READ(a1[3], aa1, 1536);
         G1_DS_READ(b1[0], bb1, 0);
         G1_DS_READ(b1[1], bb1, 2048);
         G1_DS_READ(b1[2], bb1, 4096);
@@ -336,40 +237,51 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16_dma(const GemmParams p) {
         if (t == 123.456f) reinterpret_cast<float*>(p.out)[0] = t;
         return;
     }
+    // ---- epilogue: this lane owns features [nb, nb + 16) of tokens m0 + 64 wm + 16 ni + frow
+    const int nb = n0 + wn * 64 + fg * 16;
     f32x4 bias[4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-        const int n = n0 + wn * 64 + mi * 16 + fg * 4;
         bias[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) bias[mi] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.bias && nb + 4 * mi < p.N) bias[mi] = *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * mi);
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const long long m = m0 + wm * 64 + ni * 16 + frow;
         if (m >= p.M) continue;
+        const size_t o = (size_t)m * p.N + nb;
         f32x4 r[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-            const int n = n0 + wn * 64 + mi * 16 + fg * 4;
             r[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.res && n < p.N) r[mi] = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.N + n);
+            if (p.res && nb + 4 * mi < p.N) r[mi] = *reinterpret_cast<const f32x4*>(p.res + o + 4 * mi);
         }
+        f32x4 v[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-            const int n = n0 + wn * 64 + mi * 16 + fg * 4;
-            if (n >= p.N) continue;
-            f32x4 v = acc[mi][ni] + bias[mi];
+            v[mi] = acc[mi][ni] + bias[mi];
             if (p.act == ISC_ACT_GELU) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+                for (int q = 0; q < 4; ++q) v[mi][q] = gelu_fast(v[mi][q]);
             }
-            v += r[mi];
-            const size_t o = (size_t)m * p.N + n;
-            if (p.out_f32) {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
-            } else {
-                half4 h = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(p.out) + (p.out_packed ? pk_offset(m, n, p.N) : o)) = h;
+            v[mi] += r[mi];
+        }
+        if (p.out_f32) {
+            float* dst = reinterpret_cast<float*>(p.out) + o;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                if (nb + 4 * mi < p.N) *reinterpret_cast<f32x4*>(dst + 4 * mi) = v[mi];
+        } else {
+            _Float16* dst = reinterpret_cast<_Float16*>(p.out) + (p.out_packed ? pk_offset(m, nb, p.N) : o);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 lo = v[2 * h], hi = v[2 * h + 1];
+                if (nb + 8 * h + 8 <= p.N) {
+                    *reinterpret_cast<half8*>(dst + 8 * h) = half8{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3],
+                                                                   (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]};
+                } else if (nb + 8 * h + 4 <= p.N) {
+                    *reinterpret_cast<half4*>(dst + 8 * h) = half4{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3]};
+                }
             }
         }
     }
@@ -878,13 +790,8 @@ extern "C" int isc_gemm_f16(const void* a, int64_t M, int K, const void* w, int 
         else if (dbg == 3) hipLaunchKernelGGL(k_gemm_f16_big<3>, dim3((unsigned)grid2), dim3(256), 0, s, p);
         else hipLaunchKernelGGL(k_gemm_f16_big<0>, dim3((unsigned)grid2), dim3(256), 0, s, p);
     } else {
-        static const bool regs = [] {
-            const char* e = getenv("ISC_GEMM_KERNEL");  // A/B aid: "regs" = the register-staged 128 x 128 kernel
-            return e && e[0] == 'r';
-        }();
         const long long grid1 = isc_ceil_div<long long>(tiles, 8) * 8;
-        if (regs) hipLaunchKernelGGL((k_gemm_f16<128, 128>), dim3((unsigned)grid1), dim3(256), 0, s, p);
-        else {
+        {
             static const int dbg1 = [] {
                 const char* e = getenv("ISC_GEMM_DEBUG");
                 return e ? atoi(e) : 0;

@@ -5,7 +5,7 @@ The reference has no ViT (its encoder is torchvision EfficientNetV2, src/imagesc
 is the build's own definition behind the same `EmbeddingModule` contract.  State dicts use timm's
 `vit_base_patch16_224` parameter names (`cls_token`, `pos_embed`, `patch_embed.proj.weight`, `blocks.3.attn.qkv.weight`,
 `blocks.3.mlp.fc1.bias`, `norm.weight`, ...) so such a checkpoint drops in.  The embedding of an image is the class
-token after the final LayerNorm (pre-LN encoder, exact-erf GELU, LayerNorm eps 1e-6 by default).
+token after the final LayerNorm (pre-LN encoder, erf-form GELU, LayerNorm eps 1e-6 by default).
 """
 
 from __future__ import annotations

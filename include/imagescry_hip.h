@@ -179,7 +179,7 @@ int isc_global_avgpool_nhwc(const float* x, int B, int H, int W, int C, float* y
  * rows in tiles of 256, columns in K steps of 64 halves, stored [tile][K step][row][64 halves]; a matrix of R rows
  * and C columns (C % 64 == 0) occupies ceil(R / 256) * 256 * C halves.  element (r, c) sits at
  * (((r / 256) * (C / 64) + c / 64) * 256 + r % 256) * 64 + c % 64.  One K step of one tile is 32 KiB of contiguous
- * memory, so the operand stream of a GEMM uses every L2 channel (row-major K steps are a whole row apart). */
+ * memory (one LDS-DMA instruction = one contiguous KiB), and a 64-wide attention head of a token is one 128-byte segment. */
 #define ISC_GEMM_A_PACKED 1   /* `a` is packed */
 #define ISC_GEMM_W_PACKED 2   /* `w` is packed */
 #define ISC_GEMM_OUT_PACKED 4 /* `out` (fp16 only, N % 64 == 0) is written packed */
@@ -187,7 +187,8 @@ int isc_global_avgpool_nhwc(const float* x, int B, int H, int W, int C, float* y
                                  act == ISC_ACT_NONE and operands below 4 GiB, else ISC_ERR_UNSUPPORTED */
 
 /* out[M,N] = act(a[M,K] . w[N,K]^T + bias[N]) + residual[M,N].   a, w fp16, row-major (w in torch.nn.Linear layout)
- * or packed per `flags`; bias, residual float32 row-major (either may be NULL); act ISC_ACT_NONE or ISC_ACT_GELU;
+ * or packed per `flags`; bias, residual float32 row-major (either may be NULL); act ISC_ACT_NONE or ISC_ACT_GELU
+ * (0.5 x (1 + erf(x / sqrt 2)), erf by the Abramowitz-Stegun 7.1.26 polynomial, |error| <= 1.5e-7);
  * out fp16 or float32 (`out_dtype`).  K % 64 == 0, N % 4 == 0, all pointers 16-byte aligned. */
 int isc_gemm_f16(const void* a, int64_t M, int K, const void* w, int N, const float* bias, const float* residual,
                  int act, void* out, int out_dtype, int flags, void* stream);
