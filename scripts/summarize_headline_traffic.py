@@ -21,7 +21,7 @@ src = ROOT / "gpurun_out" / f"pmc_headline_{tag}"
 
 
 def total(sub: str, counter: str) -> tuple[float, int]:
-    files = glob.glob(str(src / sub / "*/*counter_collection.csv"))
+    files = sorted(glob.glob(str(src / sub / "*/*counter_collection.csv")), key=lambda f: Path(f).stat().st_mtime, reverse=True)
     s, n = 0.0, 0
     for r in csv.DictReader(open(files[0])):
         if "k_dots_filter" in r["Kernel_Name"] and r["Counter_Name"] == counter:

@@ -18,7 +18,8 @@ ROOT = Path(__file__).resolve().parents[1]
 tag = sys.argv[1]
 src = ROOT / "gpurun_out" / f"prof_{tag}"
 out = ROOT / "profiles" / f"{tag}_summary.json"
-KERNELS = ("k_dots_filter", "k_conv_f32", "k_select", "k_rescore", "k_im2col", "k_topk_merge", "k_maxpool")
+KERNELS = ("k_dots_filter", "k_conv_f32", "k_gemm_f16", "k_attention_f16", "k_layernorm", "k_select", "k_rescore",
+           "k_topk_merge", "k_maxpool")
 
 
 def short(name: str) -> str | None:
@@ -33,19 +34,20 @@ def short(name: str) -> str | None:
 
 
 summary: dict = {"tag": tag, "kernel_stats": {}, "pmc_per_launch": {}}
-stats = glob.glob(str(src / "stats/*/*kernel_stats.csv"))
+stats = sorted(glob.glob(str(src / "stats/*/*kernel_stats.csv")), key=lambda f: Path(f).stat().st_mtime, reverse=True)
 if stats:
     for r in csv.DictReader(open(stats[0])):
         k = short(r["Name"])
-        if k:
-            summary["kernel_stats"][k] = {
-                "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2),
-                "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 3), "pct": float(r["Percentage"]),
-                "max_us": round(float(r["MaxNs"]) / 1e3, 2),
-            }
+        if k:  # template instantiations that share a short name are summed
+            e = summary["kernel_stats"].setdefault(k, {"calls": 0, "total_ms": 0.0, "pct": 0.0, "max_us": 0.0})
+            e["calls"] += int(r["Calls"])
+            e["total_ms"] = round(e["total_ms"] + float(r["TotalDurationNs"]) / 1e6, 3)
+            e["pct"] = round(e["pct"] + float(r["Percentage"]), 4)
+            e["max_us"] = max(e["max_us"], round(float(r["MaxNs"]) / 1e3, 2))
+            e["avg_us"] = round(e["total_ms"] * 1e3 / e["calls"], 2)
     (ROOT / "profiles" / f"{tag}_kernel_stats.csv").write_text(open(stats[0]).read())
 for sub in ("pmc_fetch", "pmc_write", "pmc_mfma"):
-    files = glob.glob(str(src / sub / "*/*counter_collection.csv"))
+    files = sorted(glob.glob(str(src / sub / "*/*counter_collection.csv")), key=lambda f: Path(f).stat().st_mtime, reverse=True)
     if not files:
         continue
     agg: dict = collections.defaultdict(lambda: collections.defaultdict(list))
