@@ -716,8 +716,12 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void k_select(int32_t* __restrict__
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // 1. lane maxima
+    // (trip counts are wave-uniform on purpose: `base`, not the lane's own index, bounds the loops -- step 3 counts
+    // survivors with ballots, and a lane that left the loop early would keep a stale count; the list is padded with
+    // empty keys for SEL_SLACK entries, so the over-read is harmless)
     unsigned long long lmax = 0ull;
-    for (int i0 = lane; i0 < total; i0 += 64 * 8) {
+    for (int base = 0; base < total; base += 64 * 8) {
+        const int i0 = base + lane;
         unsigned long long kk[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) kk[j] = keys[i0 + 64 * j];
@@ -742,7 +746,8 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void k_select(int32_t* __restrict__
     }
     // 3. compact the candidates >= lim (empty slots are 0 and only pass when lim == 0; they are dropped explicitly)
     int ns = 0;  // wave-uniform
-    for (int i0 = lane; i0 < total; i0 += 64 * 8) {
+    for (int base = 0; base < total; base += 64 * 8) {
+        const int i0 = base + lane;
         unsigned long long kk[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) kk[j] = keys[i0 + 64 * j];
@@ -811,7 +816,7 @@ __global__ __launch_bounds__(256) void k_rescore(const unsigned char* __restrict
                                                  const T* __restrict__ queries, int64_t ldq, int d, int kp, int k,
                                                  int64_t index_base, const int32_t* __restrict__ carry_r,
                                                  const int32_t* __restrict__ carry_n, float* __restrict__ out_s,
-                                                 int64_t* __restrict__ out_i) {
+                                                 int64_t* __restrict__ out_i, int n_rows, int32_t* __restrict__ status) {
     __shared__ float sc[128];
     __shared__ int rw[128];
     __shared__ double qnorm_sh;
@@ -835,6 +840,14 @@ __global__ __launch_bounds__(256) void k_rescore(const unsigned char* __restrict
     const double denom = qnorm_sh;
     for (int c = wave; c < n; c += 4) {
         const int row = carry_r[(size_t)q * kp + c];
+        if ((unsigned)row >= (unsigned)n_rows) {  // cannot happen; if it ever does, never touch the bank with it:
+            if (lane == 0) {                      // drop the entry and make the caller rerun on the exhaustive kernel
+                sc[c] = -INFINITY;
+                rw[c] = -1;
+                atomicAdd(&status[0], 1);
+            }
+            continue;
+        }
         double acc = 0.0;
         for (int i = lane; i < d; i += 64) acc = fma((double)qp[i], (double)isc_packed_load<T>(bank, row, i, ks), acc);
         acc = isc_wave_sum(acc);
@@ -903,7 +916,7 @@ int run(const void* bank, int64_t n, int d, const void* queries, int q, int64_t 
         if (l.r1 >= n) break;
     }
     hipLaunchKernelGGL(k_rescore<T>, dim3(q), dim3(256), 0, stream, bank_bytes, ksteps, static_cast<const T*>(queries),
-                       ldq, d, p.kp, k, index_base, w.carry_r, w.carry_n, out_s, out_i);
+                       ldq, d, p.kp, k, index_base, w.carry_r, w.carry_n, out_s, out_i, (int)n, status);
     return isc_launch_status();
 }
 

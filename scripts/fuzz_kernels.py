@@ -1,0 +1,191 @@
+"""Randomised differential tests of the non-search kernels against torch CPU / the oracle, on the GPU.
+
+    python scripts/fuzz_kernels.py [seconds per family] [seed]
+
+Families: normalize_per_channel, resize, conv2d (NHWC implicit GEMM, all epilogues), fp16 GEMM (both layouts, both
+kernels), attention, layernorm.  Prints every failing configuration; exit status 1 if there was one.
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.nn.functional as F
+from imagescry_amd import _lib, normalize_per_channel, resize
+from imagescry_amd.embedding import _conv
+from imagescry_amd.resnet50 import FoldedConv
+from imagescry_amd.vit import pack_rows, packed_elems, unpack_rows
+from oracle import transforms_oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device("cuda:0")
+lib = _lib.load()
+fails = 0
+
+
+def report(family, ok, desc):
+    global fails
+    if not ok:
+        fails += 1
+        print(f"FAIL {family}: {desc}", flush=True)
+
+
+def gen():
+    return torch.Generator().manual_seed(int(rng.integers(1 << 31)))
+
+
+def run_family(name, fn):
+    t_end, n = time.time() + budget, 0
+    while time.time() < t_end:
+        fn()
+        n += 1
+    print(f"{name}: {n} cases", flush=True)
+
+
+def f_normalize():
+    b, c = int(rng.integers(1, 9)), int(rng.integers(1, 5))
+    h, w = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+    if b * h * w < 2:
+        w += 1
+    g = gen()
+    x = torch.randint(0, 256, (b, c, h, w), dtype=torch.uint8, generator=g)
+    if rng.random() < 0.3:
+        x = x.float() * 0.37 - 11.0
+    kw = {}
+    if rng.random() < 0.6:
+        kw = {"min_value": -3.0, "max_value": 3.0}
+    exp = transforms_oracle.normalize_per_channel(x, **kw)
+    got = normalize_per_channel(x.to(dev), **kw).cpu()
+    report("normalize", torch.allclose(got, exp, rtol=0, atol=4e-6), f"{tuple(x.shape)} {x.dtype} {kw} max err {(got - exp).abs().max():.3g}")
+
+
+def f_resize():
+    b, c = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    h, w = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+    g = gen()
+    x = torch.randint(0, 256, (b, c, h, w), dtype=torch.uint8, generator=g)
+    if rng.random() < 0.3:
+        x = x.float() / 3
+    if rng.random() < 0.5:
+        size = (int(rng.integers(1, 120)), int(rng.integers(1, 120)))
+        kw = {}
+    else:
+        size = int(rng.integers(1, 150))
+        kw = {"side_ref": str(rng.choice(["long", "short", "height", "width"]))}
+    try:
+        exp = transforms_oracle.resize(x, size, **kw)
+    except Exception as e:  # a degenerate output size: the product must refuse it too
+        try:
+            resize(x.to(dev), size, **kw)
+            report("resize", False, f"{tuple(x.shape)} -> {size} {kw}: oracle raised {type(e).__name__}, product did not")
+        except Exception:
+            pass
+        return
+    got = resize(x.to(dev), size, **kw).cpu()
+    ok = got.shape == exp.shape and torch.allclose(got, exp, rtol=2e-6, atol=2e-5)
+    report("resize", ok, f"{tuple(x.shape)} {x.dtype} -> {size} {kw}: shapes {tuple(got.shape)} / {tuple(exp.shape)}")
+
+
+def f_conv():
+    b = int(rng.integers(1, 4))
+    h, w = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+    cin = int(rng.choice([32, 64, 96, 160, 256]))
+    cout = int(rng.choice([4, 24, 64, 100, 128, 132, 256, 320]))
+    k = int(rng.choice([1, 1, 3, 3, 5]))
+    stride = int(rng.choice([1, 1, 2]))
+    pad = int(rng.choice([0, k // 2]))
+    if h + 2 * pad < k or w + 2 * pad < k:
+        return
+    g = gen()
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    act_name = str(rng.choice(["none", "relu", "silu", "sigmoid", "gelu"]))
+    res_mode = str(rng.choice(["no", "before", "after"]))
+    y = F.conv2d(x, wt, bias, stride=stride, padding=pad)
+    res = torch.randn(y.shape, generator=g) if res_mode != "no" else None
+    fn = {"none": lambda t: t, "relu": F.relu, "silu": F.silu, "sigmoid": torch.sigmoid, "gelu": F.gelu}[act_name]
+    exp = fn(y + res) if res_mode == "before" else fn(y) + (res if res is not None else 0)
+    act = {"none": 0, "relu": 1, "gelu": 2, "silu": 3, "sigmoid": 4}[act_name] | (_lib.ISC_ACT_RESIDUAL_AFTER if res_mode == "after" else 0)
+    conv = FoldedConv(wt.permute(0, 2, 3, 1).contiguous().to(dev), bias.to(dev), k, stride, pad)
+    rn = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev)
+    got = _conv(x.permute(0, 2, 3, 1).contiguous().to(dev), conv, act, residual=rn).permute(0, 3, 1, 2).cpu()
+    err = float((got - exp).abs().max() / exp.abs().max().clamp_min(1e-30))
+    report("conv", got.shape == exp.shape and err < 2e-5,
+           f"b{b} {h}x{w} cin{cin} cout{cout} k{k} s{stride} p{pad} {act_name} res={res_mode}: rel err {err:.3g}")
+
+
+def f_gemm():
+    m = int(rng.choice([1, 7, 128, 129, 255, 300, 513, 1100]))
+    k = int(rng.choice([64, 128, 192, 320, 768]))
+    n = int(rng.choice([4, 64, 68, 128, 192, 256, 260, 768]))
+    pk = bool(rng.random() < 0.5)
+    out_f32 = bool(rng.random() < 0.5)
+    tile256 = bool(rng.random() < 0.3) and k >= 192
+    gelu = bool(rng.random() < 0.4) and not tile256
+    res = bool(rng.random() < 0.5)
+    if pk and not out_f32 and n % 64:
+        out_f32 = True
+    g = gen()
+    a = torch.randn(m, k, generator=g).half()
+    w = (torch.randn(n, k, generator=g) * 0.05).half()
+    bias = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g) if res else None
+    want = a.double() @ w.double().T + bias.double()
+    if gelu:
+        want = F.gelu(want)
+    if res:
+        want = want + r.double()
+    ad, wd, bd = (pack_rows(a) if pk else a).to(dev), (pack_rows(w) if pk else w).to(dev), bias.to(dev)
+    rd = r.to(dev) if res else None
+    flags = (3 | (0 if out_f32 else 4)) if pk else 0
+    flags |= 8 if tile256 else 0
+    out = torch.full((packed_elems(m, n) if pk and not out_f32 else m * n,), float("nan"),
+                     dtype=torch.float32 if out_f32 else torch.float16, device=dev)
+    st = lib.isc_gemm_f16(ad.data_ptr(), m, k, wd.data_ptr(), n, bd.data_ptr(), _lib.ptr(rd), 2 if gelu else 0,
+                          out.data_ptr(), _lib.ISC_F32 if out_f32 else _lib.ISC_F16, flags, _lib.stream_handle(dev))
+    _lib.check(st, "isc_gemm_f16")
+    got = (unpack_rows(out.cpu(), m, n) if pk and not out_f32 else out.cpu().view(m, n)).double()
+    tol = dict(rtol=1e-4, atol=1e-4) if out_f32 else dict(rtol=2e-3, atol=1e-3)
+    report("gemm", torch.allclose(got, want, **tol),
+           f"m{m} k{k} n{n} packed={pk} f32={out_f32} tile256={tile256} gelu={gelu} res={res}: max err {(got - want).abs().max():.3g}")
+
+
+def f_attention():
+    b, t, heads = int(rng.integers(1, 4)), int(rng.choice([1, 2, 15, 16, 17, 50, 197, 223, 224])), int(rng.integers(1, 5))
+    pk = bool(rng.random() < 0.5)
+    d = heads * 64
+    g = gen()
+    qkv = (torch.randn(b, t, 3 * d, generator=g) * 1.5).half()
+    q, k, v = (z.reshape(b, t, heads, 64).transpose(1, 2).double() for z in qkv.split(d, dim=-1))
+    want = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).transpose(1, 2).reshape(b, t, d)
+    qd = (pack_rows(qkv.reshape(b * t, 3 * d)) if pk else qkv).to(dev)
+    out = torch.full((packed_elems(b * t, d) if pk else b * t * d,), float("nan"), dtype=torch.float16, device=dev)
+    _lib.check(lib.isc_attention_f16(qd.data_ptr(), b, t, heads, 64, out.data_ptr(), int(pk), _lib.stream_handle(dev)), "att")
+    got = (unpack_rows(out, b * t, d) if pk else out).view(b, t, d).double().cpu()
+    report("attention", torch.allclose(got, want, rtol=4e-3, atol=2e-3), f"b{b} t{t} heads{heads} packed={pk}: max err {(got - want).abs().max():.3g}")
+
+
+def f_layernorm():
+    rows, d = int(rng.integers(1, 600)), int(rng.choice([4, 64, 192, 768, 1024, 2048]))
+    pk = bool(rng.random() < 0.5) and d % 64 == 0
+    f32 = bool(rng.random() < 0.5) and not pk
+    g = gen()
+    x = torch.randn(rows, d, generator=g) * 3 + 1.5
+    gamma, beta = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g)
+    want = F.layer_norm(x, (d,), gamma, beta, 1e-6)
+    xd, gd, bd = x.to(dev), gamma.to(dev), beta.to(dev)
+    out = torch.empty(packed_elems(rows, d) if pk else rows * d, dtype=torch.float32 if f32 else torch.float16, device=dev)
+    st = lib.isc_layernorm(xd.data_ptr(), rows, d, d, gd.data_ptr(), bd.data_ptr(), 1e-6, out.data_ptr(),
+                           _lib.ISC_F32 if f32 else _lib.ISC_F16, d, int(pk), _lib.stream_handle(dev))
+    _lib.check(st, "isc_layernorm")
+    got = (unpack_rows(out, rows, d) if pk else out.view(rows, d)).float().cpu()
+    tol = dict(rtol=1e-5, atol=1e-5) if f32 else dict(rtol=1e-3, atol=2e-3)
+    report("layernorm", torch.allclose(got, want, **tol), f"rows{rows} d{d} packed={pk} f32={f32}: max err {(got - want).abs().max():.3g}")
+
+
+for name, fn in (("normalize", f_normalize), ("resize", f_resize), ("conv", f_conv), ("gemm", f_gemm),
+                 ("attention", f_attention), ("layernorm", f_layernorm)):
+    run_family(name, fn)
+print(f"{fails} failures", flush=True)
+sys.exit(1 if fails else 0)

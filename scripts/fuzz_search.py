@@ -1,0 +1,70 @@
+"""Randomised differential test of EmbeddingBank.search against the C oracle (oracle/c/search_oracle.c) on the GPU.
+
+Not part of the pytest suites (those use fixed cases); run through gpurun:  python scripts/fuzz_search.py [seconds] [seed]
+Every case: random N, D, Q, k around the kernel's tile / level / padding boundaries, fp16 or fp32 bank, optional
+duplicated rows (exact ties), optional adversarial ordering (scores rising with the row index: candidate buffers
+overflow and the exhaustive fallback has to answer), optional index_base.  Indices must match exactly, scores to 1e-6.
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from imagescry_amd import EmbeddingBank
+from oracle import c_oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+dev = torch.device("cuda:0")
+NS = [1, 2, 15, 16, 17, 255, 256, 257, 511, 513, 4095, 4096, 4097, 5000, 12345, 40000]
+DS = [1, 3, 31, 32, 33, 63, 64, 65, 100, 128, 384, 768, 1000]
+QS = [1, 2, 15, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300]
+KS = [1, 2, 9, 10, 16, 17, 58, 100, 120]
+t_end = time.time() + budget
+cases = fails = fallbacks = 0
+worst = 0.0
+while time.time() < t_end:
+    n = int(rng.choice(NS)) if rng.random() < 0.8 else int(rng.integers(1, 60000))
+    d = int(rng.choice(DS))
+    q = int(rng.choice(QS))
+    if rng.random() < 0.08:  # cross the third level boundary (262144 rows) with a cheap shape
+        n, d, q = int(rng.integers(262000, 300000)), int(rng.choice([32, 64, 96])), int(rng.choice([1, 3, 130]))
+    while n * q * d > 2.5e9:
+        q = max(1, q // 2)
+    k = int(rng.choice([kk for kk in KS if kk <= n]))
+    dtype = torch.float16 if rng.random() < 0.6 else torch.float32
+    mode = rng.choice(["random", "random", "dup", "ordered"])
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 31)))
+    bank = torch.randn(n, d, generator=g)
+    queries = torch.randn(q, d, generator=g)
+    if mode == "dup" and n > 4:
+        src = torch.randint(0, n, (n // 3,), generator=g)
+        dst = torch.randint(0, n, (n // 3,), generator=g)
+        bank[dst] = bank[src]
+    if mode == "ordered":  # every row is the same direction, scaled up with the row index: each new tile beats the threshold
+        base = torch.randn(d, generator=g)
+        bank = base[None, :] * torch.linspace(0.5, 1.5, n)[:, None] + 0.01 * bank
+        queries = base[None, :] + 0.1 * queries
+    if rng.random() < 0.15 and q > 1:
+        queries[int(rng.integers(q))] = 0  # zero query: every score is 0, pure index order
+    normalize = bool(rng.random() < 0.5) and mode != "ordered"
+    base_idx = int(rng.choice([0, 0, 7, 1 << 33]))
+    eb = EmbeddingBank(bank.to(dev), dtype=dtype, normalize=normalize, index_base=base_idx, presharded=base_idx != 0)
+    qd = queries.to(dev)
+    s, i = eb.search(qd, k)
+    fallbacks += int(eb.last_status[0].item() != 0)
+    stored = eb.bank.cpu().float().numpy()
+    qcast = queries.to(dtype).float().numpy()
+    exp_s, exp_i = c_oracle.cosine_topk(stored, qcast, k, index_base=base_idx)
+    got_s, got_i = s.cpu().numpy(), i.cpu().numpy()
+    cases += 1
+    diff = float(np.abs(got_s - exp_s).max()) if got_s.size else 0.0
+    worst = max(worst, diff)
+    if not np.array_equal(got_i, exp_i) or diff > 1e-6:
+        fails += 1
+        bad = int((got_i != exp_i).sum())
+        print(f"FAIL n={n} d={d} q={q} k={k} {dtype} mode={mode} normalize={normalize} base={base_idx}: "
+              f"{bad} index mismatches, max score diff {diff:.3g}", flush=True)
+    del eb
+print(f"{cases} cases, {fails} failures, {fallbacks} took the exhaustive fallback, worst score diff {worst:.3g}", flush=True)
+sys.exit(1 if fails else 0)

@@ -243,3 +243,48 @@ def test_bank_from_reference_database(tmp_path, device: torch.device) -> None:
     _check(scores, indices, exp_s, exp_i)
     assert indices[:, 0].cpu().tolist() == [3, 7, 16]
     assert bank.row_origin[indices[2, 0].item()].tolist() == [9, 2, 2]
+
+
+@pytest.mark.parametrize("n", [513, 520, 575, 1025, 4097 + 512 + 7])
+def test_candidate_counts_just_past_a_multiple_of_512(n: int, device: torch.device) -> None:
+    """Regression: k_select scans its candidate list 512 entries per trip; with 512 t + (1..63) candidates only some
+    lanes ran the last trip, their ballot-counted survivor total went stale and the candidates of that trip were
+    dropped (found by scripts/fuzz_search.py: row 512 of a 513-row bank never came back)."""
+    from oracle import c_oracle
+
+    bank, queries = cases.search_case(n, 33, 256, torch.float32, seed=n)
+    eb = _bank(bank, device)
+    scores, indices = eb.search(queries.to(device), 58)
+    exp_s, exp_i = c_oracle.cosine_topk(bank.numpy(), queries.numpy(), 58)
+    _check(scores, indices, exp_s, exp_i)
+    assert int(eb.last_status[0].item()) == 0
+
+
+def test_randomised_shapes_against_the_c_oracle(device: torch.device) -> None:
+    """A fixed-seed slice of scripts/fuzz_search.py: shapes around the tile, level and padding boundaries, fp16 / fp32,
+    duplicated rows, zero queries, index_base.  Indices exact, scores to 1e-6."""
+    from imagescry_amd import EmbeddingBank
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(7)
+    ns = [1, 2, 15, 16, 17, 255, 256, 257, 511, 513, 4095, 4096, 4097, 5000]
+    ds = [1, 3, 31, 32, 33, 63, 64, 65, 100, 128, 384]
+    qs = [1, 2, 15, 63, 64, 65, 127, 128, 129, 255, 256, 257]
+    ks = [1, 2, 9, 10, 16, 17, 58, 120]
+    for _ in range(60):
+        n, d, q = int(rng.choice(ns)), int(rng.choice(ds)), int(rng.choice(qs))
+        k = int(rng.choice([kk for kk in ks if kk <= n]))
+        dtype = torch.float16 if rng.random() < 0.5 else torch.float32
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 31)))
+        bank, queries = torch.randn(n, d, generator=g), torch.randn(q, d, generator=g)
+        if rng.random() < 0.3 and n > 4:
+            bank[torch.randint(0, n, (n // 3,), generator=g)] = bank[torch.randint(0, n, (n // 3,), generator=g)]
+        if rng.random() < 0.2:
+            queries[int(rng.integers(q))] = 0
+        base = int(rng.choice([0, 7, 1 << 33]))
+        eb = EmbeddingBank(bank.to(device), dtype=dtype, normalize=bool(rng.random() < 0.5), index_base=base,
+                           presharded=base != 0)
+        scores, indices = eb.search(queries.to(device), k)
+        exp_s, exp_i = c_oracle.cosine_topk(eb.bank.cpu().float().numpy(), queries.to(dtype).float().numpy(), k,
+                                            index_base=base)
+        _check(scores, indices, exp_s, exp_i)
