@@ -18,6 +18,7 @@ from oracle import transforms_oracle
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
 dev = torch.device("cuda:0")
 lib = _lib.load()
 fails = 0
@@ -184,8 +185,111 @@ def f_layernorm():
     report("layernorm", torch.allclose(got, want, **tol), f"rows{rows} d{d} packed={pk} f32={f32}: max err {(got - want).abs().max():.3g}")
 
 
+def f_dwconv():
+    b, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 24)), int(rng.integers(1, 24))
+    c = int(rng.choice([4, 32, 96, 100, 256, 960]))
+    k = int(rng.choice([3, 3, 5]))
+    stride = int(rng.choice([1, 2]))
+    pad = k // 2
+    g = gen()
+    x = torch.randn(b, c, h, w, generator=g)
+    wt = torch.randn(c, 1, k, k, generator=g) * 0.3
+    bias = torch.randn(c, generator=g)
+    act_name = str(rng.choice(["none", "silu", "relu"]))
+    fn = {"none": lambda t: t, "silu": F.silu, "relu": F.relu}[act_name]
+    exp = fn(F.conv2d(x, wt, bias, stride=stride, padding=pad, groups=c))
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = wt.reshape(c, k, k).permute(1, 2, 0).contiguous().to(dev)
+    bd = bias.to(dev)
+    ho, wo = exp.shape[-2:]
+    out = torch.empty((b, ho, wo, c), device=dev)
+    st = lib.isc_dwconv2d_nhwc(xd.data_ptr(), b, h, w, c, wd.data_ptr(), k, stride, pad, bd.data_ptr(),
+                               {"none": 0, "relu": 1, "silu": 3}[act_name], out.data_ptr(), _lib.stream_handle(dev))
+    _lib.check(st, "isc_dwconv2d_nhwc")
+    got = out.permute(0, 3, 1, 2).cpu()
+    report("dwconv", torch.allclose(got, exp, rtol=1e-5, atol=1e-5), f"b{b} {h}x{w} c{c} k{k} s{stride} {act_name}: {(got - exp).abs().max():.3g}")
+
+
+def f_gated_and_centered():
+    b, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(1, 12))
+    cin, cout = int(rng.choice([32, 96, 256])), int(rng.choice([4, 64, 100, 256]))
+    g = gen()
+    x = torch.randn(b, cin, h, w, generator=g)
+    gate = torch.rand(b, cin, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin**0.5
+    bias = torch.randn(cout, generator=g)
+    exp = F.conv2d(x * gate[:, :, None, None], wt, bias)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    out = torch.empty((b, h, w, cout), device=dev)
+    gd, wd, bd = gate.to(dev), wt.reshape(cout, cin).contiguous().to(dev), bias.to(dev)
+    st = lib.isc_conv2d_nhwc_gated(xd.data_ptr(), b, h, w, cin, gd.data_ptr(), wd.data_ptr(), cout, 1, 1, 1, 0, bd.data_ptr(),
+                                   None, 0, out.data_ptr(), _lib.stream_handle(dev))
+    _lib.check(st, "isc_conv2d_nhwc_gated")
+    got = out.permute(0, 3, 1, 2).cpu()
+    err = float((got - exp).abs().max() / exp.abs().max().clamp_min(1e-30))
+    report("gated conv", err < 2e-5, f"b{b} {h}x{w} cin{cin} cout{cout}: rel err {err:.3g}")
+    # PCA projection: (x - mean) . w^T + bias
+    n, f, k = int(rng.integers(1, 700)), int(rng.choice([32, 64, 1280])), int(rng.choice([4, 8, 64, 100]))
+    xx, mean = torch.randn(n, f, generator=g) + 2.0, torch.randn(f, generator=g)
+    ww = torch.randn(k, f, generator=g) / f**0.5
+    exp2 = (xx - mean) @ ww.T
+    xd2, md, wd2 = xx.to(dev), mean.to(dev), ww.to(dev)
+    out2 = torch.empty((n, k), device=dev)
+    _lib.check(lib.isc_linear_centered(xd2.data_ptr(), n, f, md.data_ptr(), wd2.data_ptr(), k, None, out2.data_ptr(),
+                                       _lib.stream_handle(dev)), "isc_linear_centered")
+    err2 = float((out2.cpu() - exp2).abs().max() / exp2.abs().max().clamp_min(1e-30))
+    report("linear_centered", err2 < 2e-5, f"n{n} f{f} k{k}: rel err {err2:.3g}")
+
+
+def f_pools_l2norm():
+    b, h, w, c = int(rng.integers(1, 4)), int(rng.integers(1, 30)), int(rng.integers(1, 30)), int(rng.choice([4, 64, 100, 256]))
+    g = gen()
+    x = torch.randn(b, c, h, w, generator=g)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    s = _lib.stream_handle(dev)
+    if h >= 2 and w >= 2:
+        exp = F.max_pool2d(x, 3, 2, 1)
+        ho, wo = exp.shape[-2:]
+        out = torch.empty((b, ho, wo, c), device=dev)
+        _lib.check(lib.isc_maxpool_nhwc(xd.data_ptr(), b, h, w, c, 3, 2, 1, out.data_ptr(), s), "isc_maxpool_nhwc")
+        report("maxpool", torch.equal(out.permute(0, 3, 1, 2).cpu(), exp), f"b{b} {h}x{w} c{c}")
+    avg = torch.empty((b, c), device=dev)
+    _lib.check(lib.isc_global_avgpool_nhwc(xd.data_ptr(), b, h, w, c, avg.data_ptr(), s), "isc_global_avgpool_nhwc")
+    report("avgpool", torch.allclose(avg.cpu(), x.mean((2, 3)), rtol=1e-5, atol=1e-6), f"b{b} {h}x{w} c{c}")
+    from imagescry_amd import l2_normalize_channels
+    got = l2_normalize_channels(x.to(dev)).cpu()
+    report("l2norm", torch.allclose(got, F.normalize(x, dim=1), rtol=1e-5, atol=1e-6), f"b{b} c{c} {h}x{w}")
+    got2 = l2_normalize_channels(xd.permute(0, 3, 1, 2)).cpu()  # channels-last view: the row-normalising path
+    report("l2norm nhwc", torch.allclose(got2, F.normalize(x, dim=1), rtol=1e-5, atol=1e-6), f"b{b} c{c} {h}x{w}")
+
+
+def f_merge():
+    gq, q = int(rng.integers(1, 9)), int(rng.integers(1, 40))
+    kin = int(rng.choice([1, 5, 10, 16, 100]))
+    kout = int(rng.integers(1, min(120, gq * kin) + 1))
+    g = gen()
+    sc = torch.randn(gq, q, kin, generator=g)
+    if rng.random() < 0.5:
+        sc = (sc * 2).round() / 2  # many exact ties
+    ix = torch.randint(0, 1 << 40, (gq, q, kin), generator=g)
+    if rng.random() < 0.3:
+        sc[0, :, -1] = -float("inf")
+        ix[0, :, -1] = torch.iinfo(torch.int64).max
+    from oracle import search_oracle
+    exp_s, exp_i = search_oracle.topk_merge(sc.numpy(), ix.numpy(), kout)
+    sd, idd = sc.to(dev), ix.to(dev)
+    out_s = torch.empty((q, kout), device=dev)
+    out_i = torch.empty((q, kout), dtype=torch.int64, device=dev)
+    _lib.check(lib.isc_topk_merge(sd.data_ptr(), idd.data_ptr(), gq, q, kin, kout, 0, 0, out_s.data_ptr(), out_i.data_ptr(),
+                                  _lib.stream_handle(dev)), "isc_topk_merge")
+    ok = np.array_equal(out_i.cpu().numpy(), exp_i) and np.array_equal(out_s.cpu().numpy(), exp_s)
+    report("merge", ok, f"G{gq} q{q} kin{kin} kout{kout}")
+
+
 for name, fn in (("normalize", f_normalize), ("resize", f_resize), ("conv", f_conv), ("gemm", f_gemm),
-                 ("attention", f_attention), ("layernorm", f_layernorm)):
-    run_family(name, fn)
+                 ("attention", f_attention), ("layernorm", f_layernorm), ("dwconv", f_dwconv),
+                 ("gated conv + linear_centered", f_gated_and_centered), ("pools + l2norm", f_pools_l2norm), ("merge", f_merge)):
+    if only is None or any(o in name for o in only):
+        run_family(name, fn)
 print(f"{fails} failures", flush=True)
 sys.exit(1 if fails else 0)
