@@ -261,7 +261,7 @@ constexpr int A_TILE_BYTES = TM * 128;  // 32 KiB: one K step of one bank tile
 //
 // DBG is a bring-up aid (ISC_DEBUG_MODE environment variable, never set in production): 2 = no staging after the
 // prologue, 3 = staging but no MFMAs, 7 = like 2 without LDS fragment reads (the filter never fires in these), 11 = production kernel without the
-// half-row-block stagger of the wm = 1 waves (A/B aid, correct results).  Results are wrong for DBG != 0.
+// half-row-block stagger of the wm = 1 waves, 12 = production kernel with every wave issuing its own share of the LDS-DMA (A/B aids, correct results).  Results are wrong for DBG != 0.
 template <typename T, int TNQ, int DBG>
 __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* __restrict__ bank, int64_t r0,
                                                           int64_t r1, int tiles_per_chunk, int ntiles,
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         thr[n] = tau[q0 + wn * 64 + n * 16 + frow];
-        if (DBG != 0 && DBG != 11) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
+        if (DBG != 0 && DBG < 11) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
         cnt[n] = 0;
     }
 
@@ -326,17 +326,36 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     const unsigned lds_b_addr = lds_a_addr + A_ST * A_TILE_BYTES;
     const int wave_dst = wave * 1024;  // + 8192 * i: this wave's 1 KiB piece of staging round i
 
+    // SPLIT (256-query shape): only the wm = 0 waves issue LDS-DMA, twice as many each (pieces wave + 4 i instead of
+    // wave + 8 i), so the wm = 1 wave of every SIMD never waits on a vector-memory issue slot and keeps the matrix
+    // pipe fed while its partner is held up by the back-pressure of the L2 -> LDS path (+1 % at Q = 1024, +3.5 % at
+    // Q = 256; DBG 12 = every wave issues its own share, the A/B reference)
+    constexpr bool SPLIT = TNQ == 256 && DBG != 12;
     auto issue_a = [&](int step) {
         const unsigned char* src = a_stream + (int64_t)step * A_TILE_BYTES;
         unsigned char* dst = lds_a + (step % A_ST) * A_TILE_BYTES + wave_dst;
+        if constexpr (SPLIT) {
+            if (wm == 0) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) glds16(src + 8192 * i, dst + 8192 * i);
+                for (int i = 0; i < 2 * NA; ++i) glds16(src + 4096 * i, dst + 4096 * i);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) glds16(src + 8192 * i, dst + 8192 * i);
+        }
     };
     auto issue_b = [&](int step) {
         const unsigned char* src = b_stream + (int64_t)(step % ksteps) * B_TILE_BYTES;
         unsigned char* dst = lds_b + (step % B_ST) * B_TILE_BYTES + wave_dst;
+        if constexpr (SPLIT) {
+            if (wm == 0) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) glds16(src + 8192 * i, dst + 8192 * i);
+                for (int i = 0; i < 2 * NB; ++i) glds16(src + 4096 * i, dst + 4096 * i);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) glds16(src + 8192 * i, dst + 8192 * i);
+        }
     };
     // what iteration `it` issues (it < 0: prologue): first the query step, then the bank step
     auto issue_iter = [&](int it) {
@@ -352,8 +371,15 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             return;
         }
         if (TNQ == 256) {  // stream order ... B(next) A(next + 1): only A(next + 1) may stay in flight
-            if (next + 1 < total_steps) wait_vmcnt<NA>();
-            else wait_vmcnt<0>();
+            if constexpr (SPLIT) {
+                if (wm == 0) {
+                    if (next + 1 < total_steps) wait_vmcnt<2 * NA>();
+                    else wait_vmcnt<0>();
+                }
+            } else {
+                if (next + 1 < total_steps) wait_vmcnt<NA>();
+                else wait_vmcnt<0>();
+            }
         } else {  // stream order ... B(next) A(next) | B(next+1) A(next+1) | B(next+2) A(next+2)
             const int ahead = min(2, total_steps - 1 - next);
             if (ahead >= 2) wait_vmcnt<2 * (NA + NB)>();
@@ -421,7 +447,20 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             ISC_DS_READ(ar[1][0], a_addr0, 2048);  // R2
             ISC_DS_READ(ar[1][1], a_addr1, 2048);
 #define ISC_DMA(j_)                                                                 \
-    if ((j_) < 4) {                                                                 \
+    if constexpr (SPLIT) {                                                          \
+        if constexpr (!STAGGER) { /* the wm = 0 loop: two pieces per row block (issuing the whole query step in  \
+                                     block 0 instead measured 1 % slower) */        \
+            if ((j_) < 4) {                                                         \
+                if (do_b) {                                                         \
+                    glds16(bsrc + 4096 * (2 * (j_)), bdst + 4096 * (2 * (j_)));     \
+                    glds16(bsrc + 4096 * (2 * (j_) + 1), bdst + 4096 * (2 * (j_) + 1)); \
+                }                                                                   \
+            } else if (do_a) {                                                      \
+                glds16(asrc + 4096 * (2 * ((j_)-4)), adst + 4096 * (2 * ((j_)-4)));  \
+                glds16(asrc + 4096 * (2 * ((j_)-4) + 1), adst + 4096 * (2 * ((j_)-4) + 1)); \
+            }                                                                       \
+        }                                                                           \
+    } else if ((j_) < 4) {                                                          \
         if (do_b) glds16(bsrc + 8192 * (j_), bdst + 8192 * (j_));                   \
     } else {                                                                        \
         if (do_a) glds16(asrc + 8192 * ((j_)-4), adst + 8192 * ((j_)-4));           \
@@ -612,7 +651,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
         __builtin_amdgcn_s_barrier();
     }
     };
-    if (TNQ == 256 && DBG != 11 && __builtin_amdgcn_readfirstlane(wm) == 1) main_loop(std::true_type{});
+    if (TNQ == 256 && DBG != 11 && __builtin_amdgcn_readfirstlane(wm) == 1) main_loop(std::true_type{});  // DBG 12 relies on this split
     else main_loop(std::false_type{});
 
     // ---- tail: compact this lane's private survivors into the per-query list.  One returning atomic per
@@ -889,6 +928,7 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
         case 3: ISC_LAUNCH_FILTER(3); break;
         case 7: ISC_LAUNCH_FILTER(7); break;
         case 11: ISC_LAUNCH_FILTER(11); break;
+        case 12: ISC_LAUNCH_FILTER(12); break;
         default: ISC_LAUNCH_FILTER(0); break;
     }
 #undef ISC_LAUNCH_FILTER
