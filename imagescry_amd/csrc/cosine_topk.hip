@@ -923,7 +923,13 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
     hipLaunchKernelGGL((k_dots_filter<T, TNQ, DBG_>), dim3(l.nchunks, p.qtiles), dim3(NTHREADS), 0, stream, bank,    \
                        l.r0, l.r1, l.tiles_per_chunk, l.ntiles, w.qpacked, ksteps, w.tau, p.qpad, w.seg_ent,         \
                        w.qcount, w.qlist, l.r0 == 0 ? 1 : 0, status)
-    switch (debug_mode()) {
+    // SPLIT (DBG 0) pays where a chunk has ONE query tile (Q <= 256).  With several query-tile workgroups streaming the
+    // same bank rows it makes them drift further apart, and their sharing of those rows through the XCD's L2 drops
+    // (measured L2 -> fabric reads per search at Q = 1024: 3.0 x the algorithmic bytes with SPLIT, 1.6 - 2.0 x without,
+    // for +1 % speed), so those launches use the every-wave-issues form (DBG 12).
+    int mode = debug_mode();
+    if (mode == 0 && TNQ == 256 && p.qtiles > 1) mode = 12;
+    switch (mode) {
         case 2: ISC_LAUNCH_FILTER(2); break;
         case 3: ISC_LAUNCH_FILTER(3); break;
         case 7: ISC_LAUNCH_FILTER(7); break;
