@@ -261,7 +261,7 @@ constexpr int A_TILE_BYTES = TM * 128;  // 32 KiB: one K step of one bank tile
 //
 // DBG is a bring-up aid (ISC_DEBUG_MODE environment variable, never set in production): 2 = no staging after the
 // prologue, 3 = staging but no MFMAs, 7 = like 2 without LDS fragment reads (the filter never fires in these), 11 = production kernel without the
-// half-row-block stagger of the wm = 1 waves, 12 = production kernel with every wave issuing its own share of the LDS-DMA (A/B aids, correct results).  Results are wrong for DBG != 0.
+// half-row-block stagger of the wm = 1 waves, 12 = production kernel with every wave issuing its own share of the LDS-DMA (A/B aids, correct results), 15 = DMA issued but never waited for.  Results are wrong for DBG != 0.
 template <typename T, int TNQ, int DBG>
 __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* __restrict__ bank, int64_t r0,
                                                           int64_t r1, int tiles_per_chunk, int ntiles,
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         thr[n] = tau[q0 + wn * 64 + n * 16 + frow];
-        if (DBG != 0 && DBG < 11) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
+        if ((DBG != 0 && DBG < 11) || DBG == 15) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
         cnt[n] = 0;
     }
 
@@ -370,6 +370,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             wait_vmcnt<0>();
             return;
         }
+        if (DBG == 15) return;  // ablation: the DMA is issued but never waited for (stale operands, wrong results)
         if (TNQ == 256) {  // stream order ... B(next) A(next + 1): only A(next + 1) may stay in flight
             if constexpr (SPLIT) {
                 if (wm == 0) {
@@ -935,6 +936,7 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
         case 7: ISC_LAUNCH_FILTER(7); break;
         case 11: ISC_LAUNCH_FILTER(11); break;
         case 12: ISC_LAUNCH_FILTER(12); break;
+        case 15: ISC_LAUNCH_FILTER(15); break;
         default: ISC_LAUNCH_FILTER(0); break;
     }
 #undef ISC_LAUNCH_FILTER
