@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         thr[n] = tau[q0 + wn * 64 + n * 16 + frow];
-        if ((DBG != 0 && DBG < 11) || DBG == 15) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
+        if ((DBG != 0 && DBG < 11) || DBG >= 15) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
         cnt[n] = 0;
     }
 
