@@ -261,7 +261,7 @@ constexpr int A_TILE_BYTES = TM * 128;  // 32 KiB: one K step of one bank tile
 //
 // DBG is a bring-up aid (ISC_DEBUG_MODE environment variable, never set in production): 2 = no staging after the
 // prologue, 3 = staging but no MFMAs, 7 = like 2 without LDS fragment reads (the filter never fires in these), 11 = production kernel without the
-// half-row-block stagger of the wm = 1 waves, 12 = production kernel with every wave issuing its own share of the LDS-DMA (A/B aids, correct results), 15 = DMA issued but never waited for.  Results are wrong for DBG != 0.
+// half-row-block stagger of the wm = 1 waves, 12 = production kernel with every wave issuing its own share of the LDS-DMA (A/B aids, correct results), 15 = DMA issued but never waited for, 17 = DMA and MFMAs but no LDS fragment reads.  Results are wrong for DBG != 0.
 template <typename T, int TNQ, int DBG>
 __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* __restrict__ bank, int64_t r0,
                                                           int64_t r1, int tiles_per_chunk, int ntiles,
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     constexpr bool STAGGER = decltype(stagger_tag)::value;
     int kt = 0, tile = 0;
     for (int step = 0; step < total_steps; ++step) {
-        if constexpr (TNQ == 256 && DBG != 7) {
+        if constexpr (TNQ == 256 && DBG != 7 && DBG != 17) {
             // ---- 256-query shape.  One K step = 8 row blocks of 8 MFMAs (fp16).  Fragment reads run two row blocks
             // ahead of the matrix cores (LDS returns in order: lgkmcnt(4) = "all but the newest two blocks"), and the
             // eight LDS-DMA instructions of this iteration are issued one per row block, so their issue cost hides
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             const unsigned a_addr0 = a_addr + foff[0], a_addr1 = a_addr + foff[1];
             const unsigned b_addr0 = b_addr + foff[0], b_addr1 = b_addr + foff[1];
             u32x4 bq[2][4], ar[2][2];
-            if constexpr (DBG == 7) {  // no LDS traffic: feed the matrix cores from whatever the registers hold
+            if constexpr (DBG == 7 || DBG == 17) {  // no LDS traffic: feed the matrix cores from whatever the registers hold
 #pragma unroll
                 for (int i = 0; i < 8; ++i) bq[i >> 2][i & 3] = u32x4{(unsigned)step, 1u, 2u, (unsigned)lane};
                 ar[0][0] = ar[0][1] = ar[1][0] = ar[1][1] = u32x4{(unsigned)lane, 3u, (unsigned)step, 5u};
@@ -937,6 +937,7 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
         case 11: ISC_LAUNCH_FILTER(11); break;
         case 12: ISC_LAUNCH_FILTER(12); break;
         case 15: ISC_LAUNCH_FILTER(15); break;
+        case 17: ISC_LAUNCH_FILTER(17); break;
         default: ISC_LAUNCH_FILTER(0); break;
     }
 #undef ISC_LAUNCH_FILTER
