@@ -14,6 +14,7 @@ from oracle import c_oracle
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+deep = len(sys.argv) > 3 and sys.argv[3] == "deep"  # banks of 5 k - 700 k rows x 129 - 600 queries: levels 1 and 2, both tile shapes
 rng = np.random.default_rng(seed)
 dev = torch.device("cuda:0")
 NS = [1, 2, 15, 16, 17, 255, 256, 257, 511, 513, 4095, 4096, 4097, 5000, 12345, 40000]
@@ -29,7 +30,13 @@ while time.time() < t_end:
     q = int(rng.choice(QS))
     if rng.random() < 0.08:  # cross the third level boundary (262144 rows) with a cheap shape
         n, d, q = int(rng.integers(262000, 300000)), int(rng.choice([32, 64, 96])), int(rng.choice([1, 3, 130]))
-    while n * q * d > 2.5e9:
+    if deep:
+        n = int(rng.integers(5000, 700000))
+        d = int(rng.choice([64, 96, 128, 192]))
+        q = int(rng.choice([64, 128, 129, 200, 256, 257, 400, 600]))
+        while n * q * d > 6e9:
+            n = max(5000, n // 2)
+    while n * q * d > (6e9 if deep else 2.5e9):
         q = max(1, q // 2)
     k = int(rng.choice([kk for kk in KS if kk <= n]))
     dtype = torch.float16 if rng.random() < 0.6 else torch.float32
