@@ -49,7 +49,7 @@ constexpr int TM = 256;        // bank rows per tile
 constexpr int NTHREADS = 512;  // 8 waves
 constexpr int CAP = 32;        // candidate slots per (segment, query); segment = (chunk, row-block wave, lane group)
 constexpr int64_t LEVEL0_ROWS = 4096;  // level 0: every score is a candidate (4096 per query)
-constexpr int LEVEL_RATIO = 64;       // each later level is 64x larger: ~kp * 64 = 1024 survivors per query
+constexpr int LEVEL_RATIO = 64;       // each later level is up to 64x larger: ~kp * 63 survivors per query (level_ratio())
 constexpr int TARGET_WGS = 256;  // one workgroup per MI355X CU (the kernel uses all 160 KiB of LDS)
 constexpr int MAX_CHUNKS = 256;
 constexpr int QCAP = 4096;  // survivors per query per level that the compact list / k_select can hold
@@ -77,19 +77,30 @@ struct Level {
 
 int plan_kp(int k) { return (int)isc_align_up((size_t)k + SLACK, 16); }
 
-int64_t level_end(int level, int64_t n) {
+// How much larger than everything before it a level may be.  A level that is R times the rows seen so far lets about
+// kp * (R - 1) rows per query pass the threshold (the kp-th best score of those earlier rows); the per-query list holds
+// QCAP of them, so R shrinks with kp to keep a 2x margin: 64 up to kp = 32 (k <= 26), 32 at kp = 64, 16 at kp = 128.
+// (With a fixed 64 every search with k > 58 on a multi-level bank overflowed the list and fell back to the exhaustive
+// kernel -- found by scripts/fuzz_search.py deep.)
+int level_ratio(int kp) {
+    int r = QCAP / 2 / kp;
+    r = r > LEVEL_RATIO ? LEVEL_RATIO : r;
+    return r < 4 ? 4 : r;
+}
+
+int64_t level_end(int level, int64_t n, int ratio) {
     int64_t e = LEVEL0_ROWS;
     for (int i = 0; i < level; ++i) {
-        if (e > n / LEVEL_RATIO + 1) return n;
-        e *= LEVEL_RATIO;
+        if (e > n / ratio + 1) return n;
+        e *= ratio;
     }
     return e < n ? e : n;
 }
 
-Level make_level(int level, int64_t n, int qtiles) {
+Level make_level(int level, int64_t n, int qtiles, int ratio) {
     Level l;
-    l.r0 = level == 0 ? 0 : level_end(level - 1, n);
-    l.r1 = level_end(level, n);
+    l.r0 = level == 0 ? 0 : level_end(level - 1, n, ratio);
+    l.r1 = level_end(level, n, ratio);
     l.ntiles = (int)isc_ceil_div<int64_t>(l.r1 - l.r0, TM);
     int want = TARGET_WGS / qtiles;
     if (want < 1) want = 1;
@@ -118,7 +129,7 @@ Plan make_plan(int64_t n, int q, int k) {
     p.qpad = p.qtiles * p.tnq;
     p.max_seg = 0;
     for (int level = 0;; ++level) {
-        const Level l = make_level(level, n, p.qtiles);
+        const Level l = make_level(level, n, p.qtiles, level_ratio(p.kp));
         if (p.segs_per_chunk * l.nchunks > p.max_seg) p.max_seg = p.segs_per_chunk * l.nchunks;
         if (l.r1 >= n) break;
     }
@@ -604,7 +615,11 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
         if (++kt == ksteps) {
             // ---- tile finished: threshold filter.  C layout of the 16x16 MFMA: column (query) = lane & 15,
             // row (bank row) = 4 * (lane >> 4) + register.  Survivors are rare once tau is warm, so the scan of a
-            // query block only runs when some lane of the wave holds one (wave-uniform branch).
+            // query block only runs when some lane of the wave holds one (wave-uniform branch).  The comparison is
+            // STRICT: tau is the kp-th best score of the rows of the earlier levels, all of which have smaller row
+            // indices, so a row that merely ties it ranks behind those kp rows (ties go to the lower index) and can
+            // never enter the list -- while ">=" let every row of a zero query, or every copy of a duplicated row,
+            // through and pushed whole calls onto the exhaustive kernel.
             kt = 0;
             const int64_t trow0 = r0 + (int64_t)(tile_begin + tile) * TM + wm * (TM / WM) + fg * 4;
 #pragma unroll
@@ -625,14 +640,14 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                             const float s = acc[m][n][r];
                             if (row < r1) dst[row - r0] = Cand{s == s ? s : -INFINITY, (int32_t)row};
                         }
-                } else if (__ballot(mx >= thr[n]) != 0ull) {
+                } else if (__ballot(mx > thr[n]) != 0ull) {
 #pragma unroll
                     for (int m = 0; m < MB; ++m)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float s = acc[m][n][r];
                             const int64_t row = trow0 + m * 16 + r;
-                            if (s >= thr[n] && row < r1) {
+                            if (s > thr[n] && row < r1) {
                                 const int pos = cnt[n]++;
                                 if (pos < CAP) my_ent[(size_t)n * 16 * CAP + pos] = Cand{s, (int32_t)row};
                             }
@@ -955,7 +970,7 @@ int run(const void* bank, int64_t n, int d, const void* queries, int q, int64_t 
     hipLaunchKernelGGL(k_pack_queries<T>, dim3(isc_ceil_div(p.qpad * ksteps * 8, 256)), dim3(256), 0, stream,
                        static_cast<const T*>(queries), ldq, q, d, ksteps, p.qpad, p.tnq, w.qpacked);
     for (int level = 0;; ++level) {
-        const Level l = make_level(level, n, p.qtiles);
+        const Level l = make_level(level, n, p.qtiles, level_ratio(p.kp));
         isc_timing_begin(ISC_KERNEL_DOTS_FILTER, stream);
         if (p.tnq == 256) launch_filter<T, 256>(l, p, w, bank_bytes, ksteps, status, stream);
         else launch_filter<T, 64>(l, p, w, bank_bytes, ksteps, status, stream);

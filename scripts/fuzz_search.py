@@ -23,6 +23,7 @@ QS = [1, 2, 15, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300]
 KS = [1, 2, 9, 10, 16, 17, 58, 100, 120]
 t_end = time.time() + budget
 cases = fails = fallbacks = 0
+by_mode = {}
 worst = 0.0
 while time.time() < t_end:
     n = int(rng.choice(NS)) if rng.random() < 0.8 else int(rng.integers(1, 60000))
@@ -52,14 +53,22 @@ while time.time() < t_end:
         base = torch.randn(d, generator=g)
         bank = base[None, :] * torch.linspace(0.5, 1.5, n)[:, None] + 0.01 * bank
         queries = base[None, :] + 0.1 * queries
+    zeroq = False
     if rng.random() < 0.15 and q > 1:
         queries[int(rng.integers(q))] = 0  # zero query: every score is 0, pure index order
+        zeroq = True
     normalize = bool(rng.random() < 0.5) and mode != "ordered"
     base_idx = int(rng.choice([0, 0, 7, 1 << 33]))
     eb = EmbeddingBank(bank.to(dev), dtype=dtype, normalize=normalize, index_base=base_idx, presharded=base_idx != 0)
     qd = queries.to(dev)
     s, i = eb.search(qd, k)
-    fallbacks += int(eb.last_status[0].item() != 0)
+    fell = int(eb.last_status[0].item() != 0)
+    fallbacks += fell
+    by_mode.setdefault(str(mode), [0, 0])
+    by_mode[str(mode)][0] += 1
+    by_mode[str(mode)][1] += fell
+    if fell and mode == "random" and os.environ.get("FUZZ_VERBOSE"):
+        print(f"fallback: n={n} d={d} q={q} k={k} {dtype} normalize={normalize} zeroq={zeroq} status={eb.last_status.tolist()}", flush=True)
     stored = eb.bank.cpu().float().numpy()
     qcast = queries.to(dtype).float().numpy()
     exp_s, exp_i = c_oracle.cosine_topk(stored, qcast, k, index_base=base_idx)
@@ -73,5 +82,6 @@ while time.time() < t_end:
         print(f"FAIL n={n} d={d} q={q} k={k} {dtype} mode={mode} normalize={normalize} base={base_idx}: "
               f"{bad} index mismatches, max score diff {diff:.3g}", flush=True)
     del eb
+print("fallbacks by mode (cases, fallbacks):", by_mode, flush=True)
 print(f"{cases} cases, {fails} failures, {fallbacks} took the exhaustive fallback, worst score diff {worst:.3g}", flush=True)
 sys.exit(1 if fails else 0)

@@ -288,3 +288,26 @@ def test_randomised_shapes_against_the_c_oracle(device: torch.device) -> None:
         exp_s, exp_i = c_oracle.cosine_topk(eb.bank.cpu().float().numpy(), queries.to(dtype).float().numpy(), k,
                                             index_base=base)
         _check(scores, indices, exp_s, exp_i)
+
+
+@pytest.mark.parametrize("k,dtype", [(100, torch.float16), (120, torch.float32), (58, torch.float16)])
+def test_large_k_on_a_multi_level_bank_stays_on_the_fast_path(k: int, dtype: torch.dtype, device: torch.device) -> None:
+    """Regression (scripts/fuzz_search.py deep): with a fixed 64x level growth every search with k > 58 over more than
+    4096 rows overflowed the per-query candidate list and silently took the exhaustive kernel.  Also a zero query and
+    duplicated rows (exact ties with the threshold) must not push the call there."""
+    from oracle import c_oracle
+
+    g = torch.Generator().manual_seed(k)
+    n, d, q = 300_000, 64, 64
+    bank = torch.randn(n, d, generator=g)
+    bank[torch.randint(0, n, (n // 3,), generator=g)] = bank[torch.randint(0, n, (n // 3,), generator=g)]
+    queries = torch.randn(q, d, generator=g)
+    queries[5] = 0
+    from imagescry_amd import EmbeddingBank
+
+    eb = EmbeddingBank(bank.to(device), dtype=dtype, normalize=True)
+    scores, indices = eb.search(queries.to(device), k)
+    assert int(eb.last_status[0].item()) == 0  # no candidate buffer overflowed
+    exp_s, exp_i = c_oracle.cosine_topk(eb.bank.cpu().float().numpy(), queries.to(dtype).float().numpy(), k)
+    _check(scores, indices, exp_s, exp_i)
+    assert indices[5].cpu().tolist() == list(range(k))  # all-zero query: every score ties at 0, index order
