@@ -139,6 +139,19 @@ def measured_traffic(config: dict) -> tuple[float | None, str | None]:
     return None, None
 
 
+def measured_encode_traffic(batch: int) -> tuple[float | None, str | None]:
+    """HBM bytes per `k_conv_f32` launch of the ResNet-50 encode step from the newest committed PMC summary for this batch
+    size (profiles/*_encode_traffic.json, scripts/pmc_encode.sh + scripts/summarize_encode_traffic.py)."""
+    for f in sorted((ROOT / "profiles").glob("*_encode_traffic.json"), reverse=True):
+        try:
+            t = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if t.get("config", {}).get("batch_per_gpu") == batch:
+            return float(t["hbm_bytes_per_launch"]), f"profiles/{f.name}"
+    return None, None
+
+
 def search_roofline(rows: int, d: int, q: int, k: int, kernel_ms_per_step: float, launches_per_step: float) -> dict:
     """Roofline entry of k_dots_filter for one search step on one rank.  Algorithmic work:
     every local bank row is read once (2 B / element) and dotted with every query."""
@@ -299,6 +312,7 @@ def bench_encode(args: argparse.Namespace, rank: int, world: int, device: torch.
     flops = float(resnet50.conv_flops(b, 224, 224))
     tflops = flops * steps / (kernel_ms / 1e3) / 1e12
     ranks = world if collective_timing else 1
+    enc_traffic, enc_traffic_src = measured_encode_traffic(b)
     return {
         "metric": "images/s encode",
         "value": round(b * ranks * steps / seconds, 1),
@@ -315,7 +329,8 @@ def bench_encode(args: argparse.Namespace, rank: int, world: int, device: torch.
             "peak": MFMA_F32_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
-            "traffic": None,
+            "traffic": enc_traffic,
+            "traffic_source": enc_traffic_src,
             "launches_per_step": launches / steps,
             "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
             "kernel_ms_per_step": round(kernel_ms / steps, 3),
