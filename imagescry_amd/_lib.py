@@ -9,18 +9,23 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 from pathlib import Path
 
 import torch
 
 LIB_NAME = "libimagescry_hip.so"
-LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
+# ISC_LIB selects another build of the same ABI (the -DISC_ABLATION library used by scripts/ for ablation runs); it is
+# never set in production
+LIB_PATH = Path(os.environ.get("ISC_LIB") or Path(__file__).resolve().parent / LIB_NAME)
 
 ISC_U8, ISC_F16, ISC_F32 = 0, 1, 2
 ISC_ACT_NONE, ISC_ACT_RELU, ISC_ACT_GELU, ISC_ACT_SILU, ISC_ACT_SIGMOID = 0, 1, 2, 3, 4
 ISC_ACT_RESIDUAL_AFTER = 0x100
 ISC_TOPK_MAX_K = 120
+ISC_SEARCH_MAX_D = 8192
+ISC_ABI_VERSION = 2
 ISC_GEMM_A_PACKED, ISC_GEMM_W_PACKED, ISC_GEMM_OUT_PACKED, ISC_GEMM_TILE_256 = 1, 2, 4, 8
 ISC_KERNEL_DOTS_FILTER, ISC_KERNEL_CONV, ISC_KERNEL_GEMM_F16 = 0, 1, 2
 
@@ -57,11 +62,13 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "isc_resize_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isc_l2norm_channels": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "isc_bank_packed_bytes": (c_int, [c_int, c_int64, c_int, POINTER(c_size_t)]),
+    "isc_bank_permutation": (c_int, [c_int64, POINTER(c_int64), POINTER(c_int64)]),
     "isc_bank_pack": (
         c_int,
-        [c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_int, c_float, c_void_p, c_int, c_void_p],
+        [c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_int64, c_int, c_float, c_void_p, c_int, c_void_p,
+         c_void_p],
     ),
-    "isc_bank_unpack": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "isc_bank_unpack": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "isc_nchw_to_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isc_conv2d_nhwc": (
         c_int,
@@ -100,7 +107,7 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "isc_cosine_topk_workspace_bytes": (c_int, [c_int, c_int64, c_int, c_int, c_int, POINTER(c_size_t)]),
     "isc_cosine_topk": (
         c_int,
-        [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p,
+        [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p,
          c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     "isc_cosine_topk_exhaustive_workspace_bytes": (c_int, [c_int, c_int64, c_int, c_int, c_int, POINTER(c_size_t)]),
@@ -138,8 +145,11 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.isc_abi_version() != 1:
-        raise HipLibraryError(f"ABI version mismatch: library reports {lib.isc_abi_version()}, binding expects 1")
+    if lib.isc_abi_version() != ISC_ABI_VERSION:
+        raise HipLibraryError(
+            f"ABI version mismatch: library reports {lib.isc_abi_version()}, binding expects {ISC_ABI_VERSION}; "
+            "rebuild it with `python -m imagescry_amd.build`"
+        )
     _lib = lib
     return lib
 

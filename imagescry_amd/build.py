@@ -19,6 +19,10 @@ OBJ = CSRC / "build"
 LIB = PKG / "libimagescry_hip.so"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# `--ablation` builds a SECOND library, libimagescry_hip_ablation.so, with -DISC_ABLATION: the kernels' wrong-result
+# bring-up variants behind ISC_DEBUG_MODE / ISC_FORCE_TILE / ISC_GEMM_DEBUG.  Select it with ISC_LIB=<path> (scripts/
+# only); the production library contains none of them (tests/test_capi_symbols.py).
+ABLATION_LIB = PKG / "libimagescry_hip_ablation.so"
 
 
 def _hipcc() -> str:
@@ -35,16 +39,19 @@ def _stale(target: Path, deps: list[Path]) -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> Path:
+def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> Path:
     hipcc = _hipcc()
-    OBJ.mkdir(exist_ok=True)
+    obj_dir = CSRC / "build_ablation" if ablation else OBJ
+    lib = ABLATION_LIB if ablation else LIB
+    flags = [*FLAGS, "-DISC_ABLATION"] if ablation else FLAGS
+    obj_dir.mkdir(exist_ok=True)
     sources = sorted(CSRC.glob("*.hip"))
     headers = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "imagescry_hip.h"]
 
     def compile_one(src: Path) -> Path:
-        obj = OBJ / (src.stem + ".o")
+        obj = obj_dir / (src.stem + ".o")
         if force or _stale(obj, [src, *headers]):
-            cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+            cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
@@ -52,14 +59,13 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, sources))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(lib), *map(str, objs)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    print(build(force="--force" in sys.argv, ablation="--ablation" in sys.argv))

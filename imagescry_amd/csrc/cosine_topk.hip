@@ -1,27 +1,38 @@
 // Brute-force cosine top-k over an embedding bank (include/imagescry_hip.h: isc_cosine_topk).
 //
-// Pipeline per call (all on one stream, no host synchronisation):
+// Pipeline per call (all on one stream, NO host synchronisation and no host-side retry -- the result is final):
 //
-//   k_pack_queries    queries -> the packed K-step-major layout of the bank (1.5 MiB at Q = 1024, L2 resident)
-//   for each level L (row ranges [0,4096), [4096,262144), [262144,16.7M), ... -- each 64x the previous):
+//   k_prep            per-query state reset + queries -> the packed K-step-major layout of the bank (L2 resident)
+//   k_dots_filter<SAMPLE>   level 0: one 256-row tile per workgroup over a prefix of the (permuted, hence evenly
+//                     sampled) bank.  Each workgroup bounds its own kp-th best score from below with the kp-th
+//                     largest of its per-slot maxima (through LDS) and emits only the scores above that bound
+//                     (~1.3 kp per query instead of 256).
+//   k_select          one workgroup per query: candidates + the carried list -> the best kp by (score desc, packed
+//                     row asc); tau <- the kp-th score.
+//   for each later level (each up to ~kp-dependent ratio x everything before it):
 //     k_dots_filter   S = bank[rows] . queries^T on the matrix cores.  The scores are never written: each lane
-//                     compares its accumulators with a per-query threshold tau (the kp-th best score of the rows
-//                     seen in the earlier levels) and appends the few survivors (score, row) to a small
-//                     per-(segment, query) buffer.  Level 0 runs with tau = -inf.
-//                     At its end every lane moves its survivors into a compact per-query list (one atomic per
-//                     lane and query block, outside the hot loop).
-//     k_select        one wave per query: survivors + the carried list -> the best kp by (score desc, row asc);
-//                     tau <- the kp-th score.
-//   k_rescore         the kp = k + slack carried candidates are re-scored EXACTLY (float64 dot, float64 query
-//                     norm), rounded to float32, ordered by (score desc, row asc); the first k are the result.
+//                     compares its accumulators with the per-query threshold tau and appends the few survivors
+//                     (score, row) to a small lane-private buffer; at its end every lane moves them into a compact
+//                     per-query list (one atomic per lane and query block, outside the hot loop).
+//     k_select        between levels
+//   k_final           one workgroup per query: last selection, then the kp = k + slack carried candidates are
+//                     re-scored EXACTLY (float64 dot, float64 query norm), rounded to float32, ordered by
+//                     (score desc, ORIGINAL row asc); the first k are the result.  A rigorous guard then checks
+//                     that no row the float32 filter dropped can belong to the answer:
+//                         float32((T + eps) / ||q||) < score_k        T = the kp-th carried filter score,
+//                         eps = Dpad * 2^-23 * ||q|| * max row norm    (bound of the fp32 accumulation error)
+//                     Queries that fail it, or whose candidate buffers overflowed, are appended to a redo list.
+//   k_exact           (search_exact.hip) the listed queries -- normally none: the kernel exits at once -- are
+//                     searched again exhaustively in float64 and their output rows overwritten.
 //
 // The matrix-core pass only has to be a superset filter; ordering and the returned scores come from the exact
-// pass, so the result does not depend on tile shape, accumulation order, chunking or sharding.
+// pass, so the result does not depend on tile shape, accumulation order, chunking, level structure or sharding.
 //
-// Data layout.  The bank is PACKED (bank_layout.h): [tile of 256 rows][K step][row][128 B], so the block one K
-// step of one tile needs is 32 KiB of contiguous HBM and a workgroup's whole chunk is one linear stream.  The
-// queries are packed the same way per call.  Both MFMA operands are "K-major", so the same staging code serves A
-// (bank rows, the streamed operand) and B (queries).  One K step is 128 bytes of every row (64 halves or 32
+// Data layout.  The bank is PACKED (bank_layout.h): [tile of 256 rows][K step][row][128 B], rows in a fixed
+// pseudo-random permutation of their original order, so the block one K step of one tile needs is 32 KiB of
+// contiguous HBM, a workgroup's whole chunk is one linear stream, and every prefix is an even sample of the bank.
+// The queries are packed the same way per call.  Both MFMA operands are "K-major", so the same staging code serves
+// A (bank rows, the streamed operand) and B (queries).  One K step is 128 bytes of every row (64 halves or 32
 // floats).  LDS tiles are [rows][128 B], the eight 16-byte chunks of a row XOR-swizzled with (row >> 1) & 7 so
 // that a ds_read_b128 of an MFMA fragment (16 rows x 4 chunks per wave) is bank-conflict free; the LDS image is
 // lane-linear in the staging order (the swizzle is applied to the LDS-DMA source address).
@@ -38,6 +49,7 @@
 
 #include "bank_layout.h"
 #include "isc_common.h"
+#include "search_common.h"
 
 namespace {
 
@@ -48,107 +60,122 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TM = 256;        // bank rows per tile
 constexpr int NTHREADS = 512;  // 8 waves
 constexpr int CAP = 32;        // candidate slots per (segment, query); segment = (chunk, row-block wave, lane group)
-constexpr int64_t LEVEL0_ROWS = 4096;  // level 0: every score is a candidate (4096 per query)
-constexpr int LEVEL_RATIO = 64;       // each later level is up to 64x larger: ~kp * 63 survivors per query (level_ratio())
 constexpr int TARGET_WGS = 256;  // one workgroup per MI355X CU (the kernel uses all 160 KiB of LDS)
-constexpr int MAX_CHUNKS = 256;
-constexpr int QCAP = 4096;  // survivors per query per level that the compact list / k_select can hold
+constexpr int QCAP = 8192;  // candidates per query per level that the compact list / the selection can hold
 constexpr int SLACK = 6;
 constexpr int SMALL_Q = 128;  // up to this many queries the 64-query tile shape is used
+constexpr int QBATCH = 1024;  // queries per pass: larger calls run as several passes over the same workspace
+constexpr int MAX_LEVELS = 12;
+constexpr int SEL_THREADS = 256;
+constexpr int SURV_CAP = 1024;  // candidates the selection's exact ranking step accepts
 
 struct Cand {
     float s;
     int32_t row;
 };
 
+struct Level {
+    int64_t r0, r1;
+    int ntiles, tiles_per_chunk, nchunks;
+    int sample;  // level 0
+};
+
 struct Plan {
     int tnq;             // queries per tile: 64 or 256
     int segs_per_chunk;  // (8 / (tnq / 64)) row-block waves x 4 lane groups
     int kp;              // candidates carried per query (>= k + SLACK, multiple of 16)
-    int qtiles;          // ceil(Q / tnq)
+    int nslots;          // level 0: per-query slots whose maxima bound the workgroup's kp-th score (0 = keep every score)
+    int qb;              // queries per pass (<= QBATCH)
+    int qtiles;          // ceil(qb / tnq)
     int qpad;            // qtiles * tnq
     int max_seg;         // segs_per_chunk * max chunks over the levels
-};
-
-struct Level {
-    int64_t r0, r1;
-    int ntiles, tiles_per_chunk, nchunks;
+    int nlevels;
+    Level levels[MAX_LEVELS];
 };
 
 int plan_kp(int k) { return (int)isc_align_up((size_t)k + SLACK, 16); }
 
-// How much larger than everything before it a level may be.  A level that is R times the rows seen so far lets about
-// kp * (R - 1) rows per query pass the threshold (the kp-th best score of those earlier rows); the per-query list holds
-// QCAP of them, so R shrinks with kp to keep a 2x margin: 64 up to kp = 32 (k <= 26), 32 at kp = 64, 16 at kp = 128.
-// (With a fixed 64 every search with k > 58 on a multi-level bank overflowed the list and fell back to the exhaustive
-// kernel -- found by scripts/fuzz_search.py deep.)
-int level_ratio(int kp) {
-    int r = QCAP / 2 / kp;
-    r = r > LEVEL_RATIO ? LEVEL_RATIO : r;
-    return r < 4 ? 4 : r;
-}
-
-int64_t level_end(int level, int64_t n, int ratio) {
-    int64_t e = LEVEL0_ROWS;
-    for (int i = 0; i < level; ++i) {
-        if (e > n / ratio + 1) return n;
-        e *= ratio;
-    }
-    return e < n ? e : n;
-}
-
-Level make_level(int level, int64_t n, int qtiles, int ratio) {
-    Level l;
-    l.r0 = level == 0 ? 0 : level_end(level - 1, n, ratio);
-    l.r1 = level_end(level, n, ratio);
-    l.ntiles = (int)isc_ceil_div<int64_t>(l.r1 - l.r0, TM);
-    int want = TARGET_WGS / qtiles;
-    if (want < 1) want = 1;
-    if (want > MAX_CHUNKS) want = MAX_CHUNKS;
-    if (want > l.ntiles) want = l.ntiles;
-    l.tiles_per_chunk = isc_ceil_div(l.ntiles, want);
-    l.nchunks = isc_ceil_div(l.ntiles, l.tiles_per_chunk);
-    return l;
-}
-
+#ifdef ISC_ABLATION
 int forced_tile() {
     static const int v = [] {
-        const char* e = getenv("ISC_FORCE_TILE");  // bring-up / benchmarking aid: 64 or 256
+        const char* e = getenv("ISC_FORCE_TILE");  // ablation builds only: 64 or 256
         return e ? atoi(e) : 0;
     }();
     return v;
 }
+#else
+constexpr int forced_tile() { return 0; }
+#endif
 
+// Level structure.  Level 0 ("sample") is one tile per workgroup: with kp <= 64 every workgroup emits ~1.35 kp
+// candidates per query (see k_dots_filter), so the number of tiles is capped to keep the per-query list at <= ~0.7
+// QCAP; with kp > 64 it is 16 tiles whose every score is kept (4096 per query).  A later level that is R times the rows
+// seen so far lets about kp * (R - 1) rows per query pass the threshold (the kp-th best score of those earlier rows --
+// the bank is stored in a pseudo-random row order, so earlier rows are an even sample); R is chosen so that this stays
+// below half the per-query list AND below 1/8 of what the lane-private segments of the level hold together.
 Plan make_plan(int64_t n, int q, int k) {
     Plan p;
-    p.tnq = q <= SMALL_Q ? 64 : 256;
+    p.qb = q < QBATCH ? q : QBATCH;
+    p.tnq = p.qb <= SMALL_Q ? 64 : 256;
     if (forced_tile() == 64 || forced_tile() == 256) p.tnq = forced_tile();
     p.segs_per_chunk = (8 / (p.tnq / 64)) * 4;
     p.kp = plan_kp(k);
-    p.qtiles = isc_ceil_div(q, p.tnq);
+    p.qtiles = isc_ceil_div(p.qb, p.tnq);
     p.qpad = p.qtiles * p.tnq;
+    p.nslots = p.kp <= 16 ? 32 : p.kp <= 32 ? 64 : p.kp <= 64 ? 128 : 0;
+    int wgs = TARGET_WGS / p.qtiles;
+    if (wgs < 1) wgs = 1;
+    const int64_t ntiles_all = isc_ceil_div<int64_t>(n, TM);
+
+    p.nlevels = 0;
     p.max_seg = 0;
-    for (int level = 0;; ++level) {
-        const Level l = make_level(level, n, p.qtiles, level_ratio(p.kp));
+    auto add = [&](int64_t r0, int64_t r1, int sample) {
+        Level& l = p.levels[p.nlevels++];
+        l.r0 = r0;
+        l.r1 = r1;
+        l.sample = sample;
+        l.ntiles = (int)isc_ceil_div<int64_t>(r1 - r0, TM);
+        int want = sample ? l.ntiles : wgs;
+        if (want > l.ntiles) want = l.ntiles;
+        l.tiles_per_chunk = isc_ceil_div(l.ntiles, want);
+        l.nchunks = isc_ceil_div(l.ntiles, l.tiles_per_chunk);
         if (p.segs_per_chunk * l.nchunks > p.max_seg) p.max_seg = p.segs_per_chunk * l.nchunks;
-        if (l.r1 >= n) break;
+    };
+    int64_t stiles = p.nslots ? (int64_t)(QCAP * 7 / 10) / (p.kp * 27 / 20) : 16;
+    if (stiles > wgs) stiles = wgs;
+    if (stiles < 1) stiles = 1;
+    if (stiles > ntiles_all) stiles = ntiles_all;
+    int64_t seen = stiles * TM < n ? stiles * TM : n;
+    add(0, seen, 1);
+    while (seen < n) {
+        const int64_t nseg = (int64_t)p.segs_per_chunk * wgs;
+        int64_t budget = QCAP / 2;
+        if (nseg * CAP / 8 < budget) budget = nseg * CAP / 8;
+        int64_t ratio = 1 + budget / p.kp;
+        if (ratio < 3) ratio = 3;
+        int64_t r1 = seen * ratio;  // multiple of TM because `seen` is
+        if (r1 > n || p.nlevels == MAX_LEVELS - 1) r1 = n;
+        add(seen, r1, 0);
+        seen = r1;
     }
     return p;
 }
 
 struct Workspace {
     float* tau;              // [qpad]
-    float* carry_s;          // [qpad][kp]
-    int32_t* carry_r;        // [qpad][kp]
+    float* carry_s;          // [qpad][kp]  filter (float32) scores of the carried candidates
+    int32_t* carry_r;        // [qpad][kp]  ... their packed rows
     int32_t* carry_n;        // [qpad]
+    int32_t* qflag;          // [qpad]      != 0: a candidate buffer of this query overflowed -> exact redo
     Cand* seg_ent;           // [max_seg][qpad][CAP]  lane-private survivor segments (written in the hot loop)
     int32_t* qcount;         // [qpad]                survivors per query of the current level
     Cand* qlist;             // [qpad][QCAP]          ... compacted at the end of k_dots_filter
     unsigned char* qpacked;  // [qtiles][ks][tnq][128 B]
+    IscExactWs exact;        // redo list + partial lists of k_exact
     size_t bytes;
 };
 
-Workspace carve(const Plan& p, int ks, void* base) {
+Workspace carve(const Plan& p, int ks, int64_t n, int k, void* base) {
     Workspace w;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -160,32 +187,41 @@ Workspace carve(const Plan& p, int ks, void* base) {
     w.carry_s = static_cast<float*>(take((size_t)p.qpad * p.kp * 4));
     w.carry_r = static_cast<int32_t*>(take((size_t)p.qpad * p.kp * 4));
     w.carry_n = static_cast<int32_t*>(take((size_t)p.qpad * 4));
+    w.qflag = static_cast<int32_t*>(take((size_t)p.qpad * 4));
     w.seg_ent = static_cast<Cand*>(take((size_t)p.max_seg * p.qpad * CAP * sizeof(Cand)));
     w.qcount = static_cast<int32_t*>(take((size_t)p.qpad * 4));
     w.qlist = static_cast<Cand*>(take((size_t)p.qpad * QCAP * sizeof(Cand)));
     w.qpacked = static_cast<unsigned char*>(take((size_t)p.qpad * ks * ISC_KSTEP_BYTES));
+    const size_t ex = isc_exact_ws_bytes(n, p.qb, k);
+    w.exact = isc_exact_ws_carve(take(ex), n, p.qb, k);
     w.bytes = off;
     return w;
 }
 
-__global__ void k_init(float* tau, int32_t* carry_n, int32_t* qcount, int q, int qpad, int32_t* status) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// Per-query state reset and query packing in one launch.
+// queries row-major [q][ldq] -> packed [qtile][K step][tnq rows][128 B]; rows >= q and columns >= d are zero.
+// One thread per 16-byte chunk; the first qpad threads also reset the per-query words.
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep(const T* __restrict__ queries, int64_t ldq, int q, int d, int ks, int qpad,
+                                              int tnq, unsigned char* __restrict__ packed, float* __restrict__ tau,
+                                              int32_t* __restrict__ carry_n, int32_t* __restrict__ qcount,
+                                              int32_t* __restrict__ qflag, int32_t* __restrict__ redo_count,
+                                              int32_t* __restrict__ exact_done, int32_t* __restrict__ status,
+                                              int zero_status) {
+    constexpr int PER = 16 / (int)sizeof(T);
+    const int total = qpad * ks * 8;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < qpad) {
         tau[i] = i < q ? -INFINITY : INFINITY;  // padding queries never pass the filter
         carry_n[i] = 0;
         qcount[i] = 0;
+        qflag[i] = 0;
     }
-    if (i < 4) status[i] = 0;
-}
-
-// queries row-major [q][ldq] -> packed [qtile][K step][tnq rows][128 B]; rows >= q and columns >= d are zero.
-// One thread per 16-byte chunk.
-template <typename T>
-__global__ __launch_bounds__(256) void k_pack_queries(const T* __restrict__ queries, int64_t ldq, int q, int d, int ks,
-                                                      int qpad, int tnq, unsigned char* __restrict__ packed) {
-    constexpr int PER = 16 / (int)sizeof(T);
-    const int total = qpad * ks * 8;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        *redo_count = 0;
+        *exact_done = 0;
+    }
+    if (zero_status && i < 4) status[i] = 0;
     if (i >= total) return;
     const int c = i & 7;
     const int row = (i >> 3) % tnq;
@@ -270,17 +306,22 @@ constexpr int A_TILE_BYTES = TM * 128;  // 32 KiB: one K step of one bank tile
 // a single staging register.  Ordering rules (cdna_hip_programming.md, "Pipelining across barriers"): a slot is
 // read one iteration after the vmcnt + barrier that retires its DMA, and refilled one barrier after its last read.
 //
-// DBG is a bring-up aid (ISC_DEBUG_MODE environment variable, never set in production): 2 = no staging after the
-// prologue, 3 = staging but no MFMAs, 7 = like 2 without LDS fragment reads (the filter never fires in these), 11 = production kernel without the
-// half-row-block stagger of the wm = 1 waves, 12 = production kernel with every wave issuing its own share of the LDS-DMA (A/B aids, correct results), 15 = DMA issued but never waited for, 17 = DMA and MFMAs but no LDS fragment reads.  Results are wrong for DBG != 0.
-template <typename T, int TNQ, int DBG>
+// SAMPLE = level 0: the workgroup owns exactly ONE tile; nothing is filtered inside the loop, the epilogue after it bounds
+// the workgroup's kp-th best score from below and emits what lies above the bound (see there).
+//
+// DBG: 0 = production, 12 = production with every wave issuing its own share of the LDS-DMA (used when several query-tile
+// workgroups stream the same chunk).  The other values exist only in -DISC_ABLATION builds (wrong results by design):
+// 2 = no staging after the prologue, 3 = staging but no MFMAs, 7 = like 2 without LDS fragment reads, 11 = no
+// half-row-block stagger of the wm = 1 waves, 15 = DMA issued but never waited for, 17 = DMA and MFMAs but no LDS
+// fragment reads.
+template <typename T, int TNQ, int DBG, bool SAMPLE>
 __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* __restrict__ bank, int64_t r0,
                                                           int64_t r1, int tiles_per_chunk, int ntiles,
                                                           const unsigned char* __restrict__ qpacked, int ksteps,
                                                           const float* __restrict__ tau, int qpad,
                                                           Cand* __restrict__ seg_ent, int32_t* __restrict__ qcount,
-                                                          Cand* __restrict__ qlist, int level0,
-                                                          int32_t* __restrict__ status) {
+                                                          Cand* __restrict__ qlist, int kp, int nslots,
+                                                          int32_t* __restrict__ qflag, int32_t* __restrict__ status) {
     constexpr int WN = TNQ / 64;              // waves along the queries
     constexpr int WM = 8 / WN;                // waves along the bank rows
     constexpr int MB = TM / WM / 16;          // 16-row blocks per wave: 8 (TNQ 256) or 2 (TNQ 64)
@@ -612,14 +653,14 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 
         }
 
+        if constexpr (!SAMPLE) {
         if (++kt == ksteps) {
             // ---- tile finished: threshold filter.  C layout of the 16x16 MFMA: column (query) = lane & 15,
             // row (bank row) = 4 * (lane >> 4) + register.  Survivors are rare once tau is warm, so the scan of a
             // query block only runs when some lane of the wave holds one (wave-uniform branch).  The comparison is
-            // STRICT: tau is the kp-th best score of the rows of the earlier levels, all of which have smaller row
-            // indices, so a row that merely ties it ranks behind those kp rows (ties go to the lower index) and can
-            // never enter the list -- while ">=" let every row of a zero query, or every copy of a duplicated row,
-            // through and pushed whole calls onto the exhaustive kernel.
+            // strict; rows that merely tie tau are dropped, which the exact pass's guard accounts for (a dropped row's
+            // filter score is <= the kp-th carried one either way) -- while ">=" let every row of a zero query, or every
+            // copy of a duplicated row, through and overflowed the buffers.
             kt = 0;
             const int64_t trow0 = r0 + (int64_t)(tile_begin + tile) * TM + wm * (TM / WM) + fg * 4;
 #pragma unroll
@@ -628,19 +669,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
                     mx = fmaxf(mx, fmaxf(fmaxf(acc[m][n][0], acc[m][n][1]), fmaxf(acc[m][n][2], acc[m][n][3])));
-                if (level0) {
-                    // level 0 (tau = -inf, at most QCAP rows): every score is a survivor and goes straight to slot
-                    // `row` of the query's list -- no counters, no compaction
-                    Cand* dst = qlist + (size_t)(q0 + wn * 64 + n * 16 + frow) * QCAP;
-#pragma unroll
-                    for (int m = 0; m < MB; ++m)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int64_t row = trow0 + m * 16 + r;
-                            const float s = acc[m][n][r];
-                            if (row < r1) dst[row - r0] = Cand{s == s ? s : -INFINITY, (int32_t)row};
-                        }
-                } else if (__ballot(mx > thr[n]) != 0ull) {
+                if (__ballot(mx > thr[n]) != 0ull) {
 #pragma unroll
                     for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -660,6 +689,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                 for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
             ++tile;
         }
+        }
 
         // retire this wave's DMA for step + 1; the barrier then publishes every wave's pieces and guarantees nobody
         // still reads the slots refilled next iteration
@@ -670,26 +700,98 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     if (TNQ == 256 && DBG != 11 && __builtin_amdgcn_readfirstlane(wm) == 1) main_loop(std::true_type{});  // DBG 12 relies on this split
     else main_loop(std::false_type{});
 
+    if constexpr (SAMPLE) {
+        // ---- level 0 epilogue (one tile per workgroup; every DMA has been retired and every wave is past the last
+        // barrier, so the LDS is free).  The 256 scores of a query are cut into `nslots` slots of 256 / nslots scores, each
+        // slot living in one lane's registers; the kp-th largest of the slot maxima, L, is a lower bound of the
+        // workgroup's kp-th best score (at least kp scores are >= L), so only scores >= L can be among the best kp of
+        // the whole bank.  With nslots ~ 2 kp about 1.35 kp scores per query pass.  nslots = 0 (kp > 64): every score
+        // is kept.  Rows past the end of the bank count as -inf.
+        const int64_t trow0 = r0 + (int64_t)tile_begin * TM + wm * (TM / WM) + fg * 4;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (trow0 + m * 16 + r >= r1) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[m][n][r] = -INFINITY;
+                }
+        if (nslots > 0) {
+            float* smax = reinterpret_cast<float*>(lds);  // [TNQ][nslots]
+            float* lbound = smax + TNQ * nslots;            // [TNQ]
+            const int gsz = TM / nslots;                    // scores per slot: 8, 4 or 2
+            const int per_lane = MB * 4 / gsz;              // slots per lane and query column
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                float* dst = smax + (size_t)(wn * 64 + n * 16 + frow) * nslots + (wm * 4 + fg) * per_lane;
+                float cur = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < MB * 4; ++e) {
+                    cur = fmaxf(cur, acc[e >> 2][n][e & 3]);
+                    if (((e + 1) & (gsz - 1)) == 0) {
+                        dst[e / gsz] = cur;
+                        cur = -INFINITY;
+                    }
+                }
+            }
+            __syncthreads();
+            // rank of every slot maximum among its query's nslots (ties by slot index: ranks are a permutation)
+            for (int id = tid; id < TNQ * nslots; id += NTHREADS) {
+                const int qc = id / nslots, sl = id - qc * nslots;
+                const float* row = smax + (size_t)qc * nslots;
+                const float v = row[sl];
+                int rank = 0;
+                for (int j = 0; j < nslots; ++j) {
+                    const float x = row[j];
+                    rank += (x > v || (x == v && j < sl)) ? 1 : 0;
+                }
+                if (rank == kp - 1) lbound[qc] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                // the filter below is "s > thr": step L down by one float so that it reads "s >= L".  Padding queries
+                // (tau = +inf, loaded into thr at kernel entry) keep +inf and emit nothing.
+                const float lb = lbound[wn * 64 + n * 16 + frow];
+                const unsigned u = __float_as_uint(lb);
+                const float below = lb == 0.f ? __uint_as_float(0x80000001u)
+                                              : __uint_as_float(lb > 0.f ? u - 1u : u + 1u);
+                if (thr[n] != INFINITY) thr[n] = lb == -INFINITY ? -INFINITY : below;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s = acc[m][n][r];
+                    if (s > thr[n]) {  // rows past the end are -inf and never pass
+                        const int pos = cnt[n]++;
+                        if (pos < CAP) my_ent[(size_t)n * 16 * CAP + pos] = Cand{s, (int32_t)(trow0 + m * 16 + r)};
+                    }
+                }
+    }
+
     // ---- tail: compact this lane's private survivors into the per-query list.  One returning atomic per
     // (lane, query block) with survivors, outside the hot loop; the order inside a list is arbitrary, the
-    // selection that follows uses a total order.  Level 0 wrote the lists directly: only the count is set.
-    if (level0) {
-        if (chunk == 0 && wm == 0 && fg == 0) {
-#pragma unroll
-            for (int n = 0; n < 4; ++n) qcount[q0 + wn * 64 + n * 16 + frow] = (int)(r1 - r0);
-        }
-        return;
-    }
+    // selection that follows uses a total order.
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int c = min(cnt[n], CAP);
-        if (cnt[n] > CAP) atomicAdd(&status[0], 1);
+        const int q = q0 + wn * 64 + n * 16 + frow;
+        if (cnt[n] > CAP) {
+            atomicAdd(&status[0], 1);
+            qflag[q] = 1;
+        }
         if (c > 0) {
-            const int q = q0 + wn * 64 + n * 16 + frow;
             const int off = atomicAdd(&qcount[q], c);
             const Cand* src = my_ent + (size_t)n * 16 * CAP;
             Cand* dst = qlist + (size_t)q * QCAP;
-            if (off + c > QCAP) atomicAdd(&status[0], 1);
+            if (off + c > QCAP) {
+                atomicAdd(&status[0], 1);
+                qflag[q] = 1;
+            }
             for (int i = 0; i < c; i += 4) {  // four independent loads per trip
                 Cand e[4];
 #pragma unroll
@@ -702,228 +804,281 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     }
 }
 
-// (score desc, row asc); entries with row < 0 are empty
-__device__ __forceinline__ bool better(float sa, int ra, float sb, int rb) {
-    if (rb < 0) return ra >= 0;
-    if (ra < 0) return false;
-    return sa > sb || (sa == sb && ra < rb);
-}
-
 // ---- selection ----------------------------------------------------------------------------------------------
-// (score, row) as one 64-bit key whose unsigned order is the search order: larger key = better candidate
-// (higher score first, then LOWER row).  Keys of distinct rows are distinct.  0 is "empty".
-__device__ __forceinline__ unsigned long long make_key(float s, int row) {
-    unsigned u = __float_as_uint(s);
-    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;  // monotone float -> unsigned
-    return ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - row);
-}
-__device__ __forceinline__ float key_score(unsigned long long k) {
-    unsigned u = (unsigned)(k >> 32);
-    u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
-    return __uint_as_float(u);
-}
-__device__ __forceinline__ int key_row(unsigned long long k) { return 0x7fffffff - (int)(unsigned)(k & 0xffffffffu); }
-__device__ __forceinline__ unsigned long long bcast_key(unsigned long long k, int src_lane) {
-    const unsigned lo = __builtin_amdgcn_readlane((unsigned)k, src_lane);
-    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(k >> 32), src_lane);
-    return ((unsigned long long)hi << 32) | lo;
-}
+// One WORKGROUP (256 threads) per query: the level's survivors plus the carried list -> the best kp by (score
+// desc, packed row asc), written to `topk` (LDS, best first).  Returns how many there are (<= kp), or -1 when the
+// ranking step's buffer would overflow (adversarial list order; the caller marks the query for the exact redo).
+//   1. every thread takes the maximum key of its strided share of the candidates;
+//   2. kp <= 64: per wave, L_w = the kp-th largest of the 64 lane maxima -- at least kp candidates of that wave's
+//      share are >= L_w -- and lim = max over the waves; kp > 64: lim = the kp-th largest of the 256 thread maxima.
+//      Either way at least kp candidates are >= lim, so the best kp all are;
+//   3. candidates >= lim (typically ~1.5 kp of them) are compacted into LDS;
+//   4. they are ranked exactly by counting larger keys.
+struct SelShared {
+    unsigned long long keys[QCAP + ISC_TOPK_MAX_K + 8 + 64];  // candidates of the level + carried list
+    unsigned long long surv[SURV_CAP];
+    unsigned long long topk[ISC_TOPK_MAX_K + 8];
+    unsigned long long wlim[SEL_THREADS];  // kp <= 64: [0..3] per-wave limits; else the 256 thread maxima
+    unsigned long long lim;
+    int ns;
+};
 
-// One WAVE per query: the level's survivors plus the carried list -> the best kp by (score desc, row asc),
-// tau <- the kp-th score.  Wave-synchronous, no workgroup barrier.
-//   1. every lane takes the maximum key of its strided share of the candidates;
-//   2. L = the kp-th largest of the 64 lane maxima: at least kp candidates are >= L, so the best kp all are;
-//   3. candidates >= L (typically ~1.3 kp of them) are compacted into LDS;
-//   4. if at most 64 remain they are ranked by 64 lane broadcasts, otherwise by repeated arg-max.
-constexpr int SEL_WAVES = 2;
-constexpr int SEL_SLACK = 8 * 64;  // the unrolled scans read up to this far past the end of the list
-__global__ __launch_bounds__(64 * SEL_WAVES) void k_select(int32_t* __restrict__ qcount, const Cand* __restrict__ qlist,
-                                                           int n_queries, int kp, float* __restrict__ tau,
-                                                           float* __restrict__ carry_s, int32_t* __restrict__ carry_r,
-                                                           int32_t* __restrict__ carry_n) {
-    __shared__ unsigned long long keys_all[SEL_WAVES][QCAP + 128 + SEL_SLACK];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int q = blockIdx.x * SEL_WAVES + wave;
-    if (q >= n_queries) return;
-    unsigned long long* keys = keys_all[wave];
-    // step 3 compacts IN PLACE: a trip loads its 512 keys into registers before it stores, and it only stores below
-    // the index it has read up to, so `surv` may alias `keys`
-    unsigned long long* surv = keys;
-
+__device__ int wg_select(SelShared& sh, int q, int kp, const int32_t* __restrict__ qcount,
+                         const Cand* __restrict__ qlist, const float* __restrict__ carry_s,
+                         const int32_t* __restrict__ carry_r, const int32_t* __restrict__ carry_n) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
     const int from_list = min(qcount[q], QCAP);
-    const int carried = carry_n[q];
+    const int carried = min(carry_n[q], kp);
     const int total = from_list + carried;
     const Cand* src = qlist + (size_t)q * QCAP;
-    for (int i0 = 0; i0 < from_list; i0 += 64 * 8) {  // eight independent coalesced loads per trip
-        Cand e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = src[min(i0 + 64 * j + lane, QCAP - 1)];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (i0 + 64 * j + lane < from_list) keys[i0 + 64 * j + lane] = make_key(e[j].s, e[j].row);
-    }
-    for (int i = lane; i < carried; i += 64)
-        keys[from_list + i] = make_key(carry_s[(size_t)q * kp + i], carry_r[(size_t)q * kp + i]);
-    for (int i = total + lane; i < total + SEL_SLACK; i += 64) keys[i] = 0ull;  // padding reads as "empty"
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (tid == 0) sh.ns = 0;
 
-    // 1. lane maxima
-    // (trip counts are wave-uniform on purpose: `base`, not the lane's own index, bounds the loops -- step 3 counts
-    // survivors with ballots, and a lane that left the loop early would keep a stale count; the list is padded with
-    // empty keys for SEL_SLACK entries, so the over-read is harmless)
+    // 1. keys into LDS, thread maxima on the fly (four independent loads per trip)
     unsigned long long lmax = 0ull;
-    for (int base = 0; base < total; base += 64 * 8) {
-        const int i0 = base + lane;
-        unsigned long long kk[8];
+    for (int i0 = tid; i0 < from_list; i0 += SEL_THREADS * 4) {
+        Cand e[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) kk[j] = keys[i0 + 64 * j];
+        for (int j = 0; j < 4; ++j) e[j] = src[min(i0 + SEL_THREADS * j, QCAP - 1)];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) lmax = kk[j] > lmax ? kk[j] : lmax;
+        for (int j = 0; j < 4; ++j)
+            if (i0 + SEL_THREADS * j < from_list) {
+                const unsigned long long key = isc_make_key(e[j].s, e[j].row);
+                sh.keys[i0 + SEL_THREADS * j] = key;
+                lmax = key > lmax ? key : lmax;
+            }
     }
-    // 2. threshold key: the kp-th largest lane maximum (0 = keep everything when kp > 64 or few lanes are filled)
-    unsigned long long lim = 0ull;
+    for (int i = tid; i < carried; i += SEL_THREADS) {
+        const unsigned long long key = isc_make_key(carry_s[(size_t)q * kp + i], carry_r[(size_t)q * kp + i]);
+        sh.keys[from_list + i] = key;
+        lmax = key > lmax ? key : lmax;
+    }
+
+    // 2. threshold key
     if (kp <= 64) {
         int rank = 0;
-        for (int j = 0; j < 64; ++j) rank += bcast_key(lmax, j) > lmax ? 1 : 0;
-        // keys are distinct, except that several lanes may be empty (0): those never reach rank kp - 1 <= 63 ...
-        const unsigned long long mine = (rank == kp - 1) ? lmax : 0ull;
-        // ... so at most one lane contributes; OR-reduce it to every lane
-        unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            lo |= __shfl_xor(lo, off, 64);
-            hi |= __shfl_xor(hi, off, 64);
+        for (int j = 0; j < 64; ++j) {
+            const unsigned long long o = isc_bcast_key(lmax, j);
+            rank += (o > lmax || (o == lmax && j < lane)) ? 1 : 0;  // empty lanes tie at 0: broken by lane
         }
-        lim = ((unsigned long long)hi << 32) | lo;
-    }
-    // 3. compact the candidates >= lim (empty slots are 0 and only pass when lim == 0; they are dropped explicitly)
-    int ns = 0;  // wave-uniform
-    for (int base = 0; base < total; base += 64 * 8) {
-        const int i0 = base + lane;
-        unsigned long long kk[8];
+        const unsigned long long mine = (rank == kp - 1) ? lmax : 0ull;  // exactly one lane has this rank
+        const unsigned long long lw = isc_wave_max_key(mine);
+        if (lane == 0) sh.wlim[wave] = lw;
+        __syncthreads();
+        unsigned long long lim = sh.wlim[0];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) kk[j] = keys[i0 + 64 * j];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool keep = kk[j] != 0ull && kk[j] >= lim;
-            const unsigned long long mask = __ballot(keep);
-            if (keep) surv[ns + __popcll(mask & ((1ull << lane) - 1ull))] = kk[j];
-            ns += __popcll(mask);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    const int rounds = min(kp, ns);
-    if (ns <= 64) {
-        // 4a. rank the survivors: lane l holds survivor l, its rank is the number of larger keys
-        const unsigned long long mine = lane < ns ? surv[lane] : 0ull;
-        int rank = 0;
-        for (int j = 0; j < ns; ++j) rank += bcast_key(mine, j) > mine ? 1 : 0;
-        if (lane < ns && rank < kp) {
-            const float sc = key_score(mine);
-            carry_s[(size_t)q * kp + rank] = sc;
-            carry_r[(size_t)q * kp + rank] = key_row(mine);
-            if (rank == kp - 1) tau[q] = sc;
-        }
+        for (int w = 1; w < SEL_THREADS / 64; ++w) lim = sh.wlim[w] > lim ? sh.wlim[w] : lim;
+        if (tid == 0) sh.lim = lim;
     } else {
-        // 4b. many survivors (clustered scores, kp > 64): repeated arg-max below the previous winner
-        unsigned long long last = ~0ull;
-        for (int r = 0; r < rounds; ++r) {
-            unsigned long long best = 0ull;
-            for (int i = lane; i < ns; i += 64) {
-                const unsigned long long kx = surv[i];
-                if (kx < last && kx > best) best = kx;
-            }
-            unsigned lo = (unsigned)best, hi = (unsigned)(best >> 32);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned olo = __shfl_xor(lo, off, 64), ohi = __shfl_xor(hi, off, 64);
-                const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
-                const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-                if (o > m) {
-                    lo = olo;
-                    hi = ohi;
-                }
-            }
-            last = ((unsigned long long)hi << 32) | lo;
-            if (lane == 0) {
-                const float sc = key_score(last);
-                carry_s[(size_t)q * kp + r] = sc;
-                carry_r[(size_t)q * kp + r] = key_row(last);
-                if (r == kp - 1) tau[q] = sc;
-            }
+        sh.wlim[tid] = lmax;
+        __syncthreads();
+        int rank = 0;
+        for (int j = 0; j < SEL_THREADS; ++j) {
+            const unsigned long long o = sh.wlim[j];
+            rank += (o > lmax || (o == lmax && j < tid)) ? 1 : 0;
+        }
+        if (rank == kp - 1) sh.lim = lmax;
+    }
+    __syncthreads();
+    const unsigned long long lim = sh.lim;
+
+    // 3. compact the candidates >= lim (trip counts are workgroup-uniform: the ballots need every lane)
+    for (int base = 0; base < total; base += SEL_THREADS) {
+        const int i = base + tid;
+        const unsigned long long key = i < total ? sh.keys[i] : 0ull;
+        const bool keep = key != 0ull && key >= lim;
+        const unsigned long long mask = __ballot(keep);
+        int wbase = 0;
+        if (lane == 0 && mask != 0ull) wbase = atomicAdd(&sh.ns, __popcll(mask));
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
+        if (keep) {
+            const int pos = wbase + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < SURV_CAP) sh.surv[pos] = key;
         }
     }
-    if (lane == 0) {
-        carry_n[q] = rounds;
+    __syncthreads();
+    const int ns = sh.ns;
+    if (ns > SURV_CAP) return -1;
+
+    // 4. exact ranks
+    for (int e = tid; e < ns; e += SEL_THREADS) {
+        const unsigned long long mine = sh.surv[e];
+        int rank = 0;
+        for (int j = 0; j < ns; ++j) rank += sh.surv[j] > mine ? 1 : 0;
+        if (rank < kp) sh.topk[rank] = mine;
+    }
+    __syncthreads();
+    return min(kp, ns);
+}
+
+// between two levels: carried list and tau of every query
+__global__ __launch_bounds__(SEL_THREADS) void k_select(int32_t* __restrict__ qcount, const Cand* __restrict__ qlist,
+                                                        int kp, float* __restrict__ tau, float* __restrict__ carry_s,
+                                                        int32_t* __restrict__ carry_r, int32_t* __restrict__ carry_n,
+                                                        int32_t* __restrict__ qflag) {
+    __shared__ SelShared sh;
+    const int q = blockIdx.x;
+    const int n = wg_select(sh, q, kp, qcount, qlist, carry_s, carry_r, carry_n);
+    const int tid = threadIdx.x;
+    if (n < 0) {  // give up on the fast path for this query: nothing more survives, k_final lists it for k_exact
+        if (tid == 0) {
+            qflag[q] = 1;
+            tau[q] = INFINITY;
+            carry_n[q] = 0;
+            qcount[q] = 0;
+        }
+        return;
+    }
+    if (tid < n) {
+        const unsigned long long key = sh.topk[tid];
+        const float sc = isc_key_score(key);
+        carry_s[(size_t)q * kp + tid] = sc;
+        carry_r[(size_t)q * kp + tid] = isc_key_row(key);
+        if (tid == kp - 1) tau[q] = sc;
+    }
+    if (tid == 0) {
+        carry_n[q] = n;
         qcount[q] = 0;  // ready for the next level
     }
 }
 
-// One workgroup per query: exact float64 re-score of the carried candidates, final order, output.
+// 16 bytes of a packed row as float64 values
 template <typename T>
-__global__ __launch_bounds__(256) void k_rescore(const unsigned char* __restrict__ bank, int ks,
-                                                 const T* __restrict__ queries, int64_t ldq, int d, int kp, int k,
-                                                 int64_t index_base, const int32_t* __restrict__ carry_r,
-                                                 const int32_t* __restrict__ carry_n, float* __restrict__ out_s,
-                                                 int64_t* __restrict__ out_i, int n_rows, int32_t* __restrict__ status) {
-    __shared__ float sc[128];
-    __shared__ int rw[128];
+struct Chunk16;
+template <>
+struct Chunk16<_Float16> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const unsigned char* p, double (&v)[8]) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(p);
+        const _Float16* h = reinterpret_cast<const _Float16*>(&raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (double)(float)h[j];
+    }
+};
+template <>
+struct Chunk16<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const unsigned char* p, double (&v)[8]) {
+        const float4 raw = *reinterpret_cast<const float4*>(p);
+        v[0] = (double)raw.x;
+        v[1] = (double)raw.y;
+        v[2] = (double)raw.z;
+        v[3] = (double)raw.w;
+    }
+};
+
+// One workgroup per query: last selection, exact float64 re-score of the carried candidates, final order, output,
+// and the guard that proves the float32 filter lost nothing (see the file header).
+template <typename T>
+__global__ __launch_bounds__(SEL_THREADS) void k_final(
+    const unsigned char* __restrict__ bank, int ks, const unsigned char* __restrict__ qpacked, int tnq, int kp, int k,
+    IscPerm pm, int64_t index_base, const float* __restrict__ norm_bound, const int32_t* __restrict__ qcount,
+    const Cand* __restrict__ qlist, const float* __restrict__ carry_s, const int32_t* __restrict__ carry_r,
+    const int32_t* __restrict__ carry_n, const int32_t* __restrict__ qflag, float* __restrict__ out_s,
+    int64_t* __restrict__ out_i, int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_list,
+    int32_t* __restrict__ status) {
+    __shared__ SelShared sh;
+    __shared__ double exact_dot[ISC_TOPK_MAX_K + 8];
+    __shared__ float fsc[ISC_TOPK_MAX_K + 8];
+    __shared__ int orig[ISC_TOPK_MAX_K + 8];
     __shared__ double qnorm_sh;
+    __shared__ float kth_sh;
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const T* qp = queries + (int64_t)q * ldq;
-    const int n = carry_n[q];
+    const int n = wg_select(sh, q, kp, qcount, qlist, carry_s, carry_r, carry_n);
+    bool redo = n < 0 || qflag[q] != 0;
+    const int nc = n < 0 ? 0 : n;
 
+    // this query's packed row: K step s at qrow_base + s * tnq * 128
+    const unsigned char* qrow_base = qpacked + ((size_t)(q / tnq) * ks * tnq + (q % tnq)) * ISC_KSTEP_BYTES;
+    const int sub = lane >> 3;  // K step within a group of 8
+    const int ch = lane & 7;    // 16-byte chunk of the K step
     if (wave == 0) {
         double acc = 0.0;
-        for (int i = lane; i < d; i += 64) {
-            const double x = (double)qp[i];
-            acc = fma(x, x, acc);
-        }
-        acc = isc_wave_sum(acc);
-        if (lane == 0) qnorm_sh = fmax(sqrt(acc), 1e-12);
-    }
-    __syncthreads();
-    const double denom = qnorm_sh;
-    for (int c = wave; c < n; c += 4) {
-        const int row = carry_r[(size_t)q * kp + c];
-        if ((unsigned)row >= (unsigned)n_rows) {  // cannot happen; if it ever does, never touch the bank with it:
-            if (lane == 0) {                      // drop the entry and make the caller rerun on the exhaustive kernel
-                sc[c] = -INFINITY;
-                rw[c] = -1;
-                atomicAdd(&status[0], 1);
+        for (int s0 = 0; s0 < ks; s0 += 8) {
+            const int s = s0 + sub;
+            if (s < ks) {
+                double v[8];
+                Chunk16<T>::load(qrow_base + (size_t)s * tnq * ISC_KSTEP_BYTES + ch * 16, v);
+#pragma unroll
+                for (int j = 0; j < Chunk16<T>::N; ++j) acc = fma(v[j], v[j], acc);
             }
-            continue;
         }
-        double acc = 0.0;
-        for (int i = lane; i < d; i += 64) acc = fma((double)qp[i], (double)isc_packed_load<T>(bank, row, i, ks), acc);
         acc = isc_wave_sum(acc);
-        if (lane == 0) {
-            sc[c] = (float)(acc / denom);
-            rw[c] = row;
+        if (lane == 0) qnorm_sh = sqrt(acc);
+    }
+    // exact dots: one wave per candidate, a lane covers the 16-byte chunk `ch` of K steps sub, sub + 8, ...
+    for (int c = wave; c < nc; c += SEL_THREADS / 64) {
+        const int row = isc_key_row(sh.topk[c]);
+        double acc = 0.0;
+        if ((unsigned)row < (unsigned)pm.n) {
+            for (int s0 = 0; s0 < ks; s0 += 8) {
+                const int s = s0 + sub;
+                if (s < ks) {
+                    double a[8], b[8];
+                    Chunk16<T>::load(bank + isc_packed_offset(row, s, ks) + ch * 16, a);
+                    Chunk16<T>::load(qrow_base + (size_t)s * tnq * ISC_KSTEP_BYTES + ch * 16, b);
+#pragma unroll
+                    for (int j = 0; j < Chunk16<T>::N; ++j) acc = fma(a[j], b[j], acc);
+                }
+            }
         }
+        acc = isc_wave_sum(acc);
+        if (lane == 0) exact_dot[c] = acc;
     }
     __syncthreads();
-    if (tid < n) {
-        const float s = sc[tid];
-        const int r = rw[tid];
+    const double qnorm = qnorm_sh;
+    const double denom = fmax(qnorm, 1e-12);
+    if (tid < nc) {
+        const int row = isc_key_row(sh.topk[tid]);
+        fsc[tid] = (float)(exact_dot[tid] / denom);
+        orig[tid] = (unsigned)row < (unsigned)pm.n ? (int)isc_perm_orig(pm, row) : 0x7ffffffe;
+        if ((unsigned)row >= (unsigned)pm.n) redo = true;  // cannot happen; never trust such an entry
+    }
+    __syncthreads();
+    // rounding-error bound of a filter score: Dpad float32 accumulation steps, each off by at most 2^-23 of the running
+    // magnitude (<= sum |q_i b_i| <= ||q|| * ||b||): one step of margin over round-to-nearest, whatever the order in
+    // which the matrix core adds its 32 products
+    const double bmax = norm_bound ? (double)*norm_bound : 1.001;
+    const double eps = (double)(ks * (ISC_KSTEP_BYTES / (int)sizeof(T))) * (1.0 / 8388608.0) * qnorm * bmax;
+    if (tid < nc) {
+        const unsigned long long mykey = isc_make_key(fsc[tid], orig[tid]);
         int rank = 0;
-        for (int j = 0; j < n; ++j) rank += better(sc[j], rw[j], s, r) ? 1 : 0;
+        for (int j = 0; j < nc; ++j) rank += isc_make_key(fsc[j], orig[j]) > mykey ? 1 : 0;
         if (rank < k) {
-            out_s[(size_t)q * k + rank] = s;
-            out_i[(size_t)q * k + rank] = (int64_t)r + index_base;
+            out_s[(size_t)q * k + rank] = fsc[tid];
+            out_i[(size_t)q * k + rank] = (int64_t)orig[tid] + index_base;
+        }
+        if (rank == k - 1) kth_sh = fsc[tid];
+        // how far the filter scores really are from the exact ones, in units of the bound (status[2], diagnostics)
+        if (eps > 0.0) {
+            const float ratio = (float)(fabs((double)isc_key_score(sh.topk[tid]) - exact_dot[tid]) / eps);
+            if (ratio == ratio) atomicMax(reinterpret_cast<unsigned*>(&status[2]), __float_as_uint(ratio));
+        }
+    }
+    redo = __syncthreads_or(redo ? 1 : 0) != 0;
+    if (tid == 0) {
+        if (!redo && (int64_t)nc < pm.n) {  // with every row of the bank carried the answer is exact as it stands
+            if (nc < kp) {
+                redo = true;  // fewer candidates than asked for although the bank has more rows (NaN scores)
+            } else {
+                const float t = isc_key_score(sh.topk[kp - 1]);  // every dropped row's filter score is <= t
+                const float bound = (float)(((double)t + eps) / denom);
+                redo = !(bound < kth_sh);
+            }
+        }
+        if (redo) {
+            const int slot = atomicAdd(redo_count, 1);
+            redo_list[slot] = q;
+            atomicAdd(&status[1], 1);
         }
     }
 }
 
+#ifdef ISC_ABLATION
 int debug_mode() {
     static const int mode = [] {
         const char* e = getenv("ISC_DEBUG_MODE");
@@ -931,14 +1086,21 @@ int debug_mode() {
     }();
     return mode;
 }
+#else
+constexpr int debug_mode() { return 0; }
+#endif
 
 template <typename T, int TNQ>
 void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsigned char* bank, int ksteps,
                    int32_t* status, hipStream_t stream) {
-#define ISC_LAUNCH_FILTER(DBG_)                                                                                      \
-    hipLaunchKernelGGL((k_dots_filter<T, TNQ, DBG_>), dim3(l.nchunks, p.qtiles), dim3(NTHREADS), 0, stream, bank,    \
-                       l.r0, l.r1, l.tiles_per_chunk, l.ntiles, w.qpacked, ksteps, w.tau, p.qpad, w.seg_ent,         \
-                       w.qcount, w.qlist, l.r0 == 0 ? 1 : 0, status)
+#define ISC_LAUNCH_FILTER(DBG_, SAMPLE_)                                                                             \
+    hipLaunchKernelGGL((k_dots_filter<T, TNQ, DBG_, SAMPLE_>), dim3(l.nchunks, p.qtiles), dim3(NTHREADS), 0, stream, \
+                       bank, l.r0, l.r1, l.tiles_per_chunk, l.ntiles, w.qpacked, ksteps, w.tau, p.qpad, w.seg_ent,   \
+                       w.qcount, w.qlist, p.kp, p.nslots, w.qflag, status)
+    if (l.sample) {  // one tile per workgroup: the staging variant does not matter
+        ISC_LAUNCH_FILTER(12, true);
+        return;
+    }
     // SPLIT (DBG 0) pays where a chunk has ONE query tile (Q <= 256).  With several query-tile workgroups streaming the
     // same bank rows it makes them drift further apart, and their sharing of those rows through the XCD's L2 drops
     // (measured L2 -> fabric reads per search at Q = 1024: 3.0 x the algorithmic bytes with SPLIT, 1.6 - 2.0 x without,
@@ -946,41 +1108,56 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
     int mode = debug_mode();
     if (mode == 0 && TNQ == 256 && p.qtiles > 1) mode = 12;
     switch (mode) {
-        case 2: ISC_LAUNCH_FILTER(2); break;
-        case 3: ISC_LAUNCH_FILTER(3); break;
-        case 7: ISC_LAUNCH_FILTER(7); break;
-        case 11: ISC_LAUNCH_FILTER(11); break;
-        case 12: ISC_LAUNCH_FILTER(12); break;
-        case 15: ISC_LAUNCH_FILTER(15); break;
-        case 17: ISC_LAUNCH_FILTER(17); break;
-        default: ISC_LAUNCH_FILTER(0); break;
+#ifdef ISC_ABLATION
+        case 2: ISC_LAUNCH_FILTER(2, false); break;
+        case 3: ISC_LAUNCH_FILTER(3, false); break;
+        case 7: ISC_LAUNCH_FILTER(7, false); break;
+        case 11: ISC_LAUNCH_FILTER(11, false); break;
+        case 15: ISC_LAUNCH_FILTER(15, false); break;
+        case 17: ISC_LAUNCH_FILTER(17, false); break;
+#endif
+        case 12: ISC_LAUNCH_FILTER(12, false); break;
+        default:
+            if constexpr (TNQ == 256) ISC_LAUNCH_FILTER(0, false);
+            else ISC_LAUNCH_FILTER(12, false);  // the 64-query shape has no SPLIT: one instantiation
+            break;
     }
 #undef ISC_LAUNCH_FILTER
 }
 
 template <typename T>
-int run(const void* bank, int64_t n, int d, const void* queries, int q, int64_t ldq, int k, int64_t index_base,
-        float* out_s, int64_t* out_i, int32_t* status, void* ws_base, hipStream_t stream) {
-    const Plan p = make_plan(n, q, k);
+int run(const void* bank, int64_t n, int d, const void* queries, int q_total, int64_t ldq, int k, int64_t index_base,
+        const float* norm_bound, float* out_s, int64_t* out_i, int32_t* status, void* ws_base, hipStream_t stream) {
+    const Plan p = make_plan(n, q_total, k);
     const int ksteps = isc_ksteps(d, (int)sizeof(T));
-    const Workspace w = carve(p, ksteps, ws_base);
+    const Workspace w = carve(p, ksteps, n, k, ws_base);
     const unsigned char* bank_bytes = static_cast<const unsigned char*>(bank);
-    hipLaunchKernelGGL(k_init, dim3(isc_ceil_div(p.qpad, 256)), dim3(256), 0, stream, w.tau, w.carry_n, w.qcount, q,
-                       p.qpad, status);
-    hipLaunchKernelGGL(k_pack_queries<T>, dim3(isc_ceil_div(p.qpad * ksteps * 8, 256)), dim3(256), 0, stream,
-                       static_cast<const T*>(queries), ldq, q, d, ksteps, p.qpad, p.tnq, w.qpacked);
-    for (int level = 0;; ++level) {
-        const Level l = make_level(level, n, p.qtiles, level_ratio(p.kp));
-        isc_timing_begin(ISC_KERNEL_DOTS_FILTER, stream);
-        if (p.tnq == 256) launch_filter<T, 256>(l, p, w, bank_bytes, ksteps, status, stream);
-        else launch_filter<T, 64>(l, p, w, bank_bytes, ksteps, status, stream);
-        isc_timing_end(ISC_KERNEL_DOTS_FILTER, stream);
-        hipLaunchKernelGGL(k_select, dim3(isc_ceil_div(q, SEL_WAVES)), dim3(64 * SEL_WAVES), 0, stream, w.qcount, w.qlist,
-                           q, p.kp, w.tau, w.carry_s, w.carry_r, w.carry_n);
-        if (l.r1 >= n) break;
+    const IscPerm pm = isc_make_perm(n);
+    for (int q0 = 0; q0 < q_total; q0 += p.qb) {
+        const int q = q_total - q0 < p.qb ? q_total - q0 : p.qb;
+        const T* qptr = static_cast<const T*>(queries) + (int64_t)q0 * ldq;
+        float* os = out_s + (size_t)q0 * k;
+        int64_t* oi = out_i + (size_t)q0 * k;
+        hipLaunchKernelGGL(k_prep<T>, dim3(isc_ceil_div(p.qpad * ksteps * 8, 256)), dim3(256), 0, stream, qptr, ldq, q,
+                           d, ksteps, p.qpad, p.tnq, w.qpacked, w.tau, w.carry_n, w.qcount, w.qflag,
+                           w.exact.redo_count, w.exact.done, status, q0 == 0 ? 1 : 0);
+        for (int li = 0; li < p.nlevels; ++li) {
+            const Level& l = p.levels[li];
+            isc_timing_begin(ISC_KERNEL_DOTS_FILTER, stream);
+            if (p.tnq == 256) launch_filter<T, 256>(l, p, w, bank_bytes, ksteps, status, stream);
+            else launch_filter<T, 64>(l, p, w, bank_bytes, ksteps, status, stream);
+            isc_timing_end(ISC_KERNEL_DOTS_FILTER, stream);
+            if (li + 1 < p.nlevels)
+                hipLaunchKernelGGL(k_select, dim3(q), dim3(SEL_THREADS), 0, stream, w.qcount, w.qlist, p.kp, w.tau,
+                                   w.carry_s, w.carry_r, w.carry_n, w.qflag);
+        }
+        hipLaunchKernelGGL(k_final<T>, dim3(q), dim3(SEL_THREADS), 0, stream, bank_bytes, ksteps, w.qpacked, p.tnq, p.kp,
+                           k, pm, index_base, norm_bound, w.qcount, w.qlist, w.carry_s, w.carry_r, w.carry_n, w.qflag, os,
+                           oi, w.exact.redo_count, w.exact.redo_list, status);
+        const int st = isc_exact_launch(sizeof(T) == 2 ? ISC_F16 : ISC_F32, bank, n, d, qptr, ldq, k, index_base,
+                                        w.exact, os, oi, status, stream);
+        if (st != ISC_OK) return st;
     }
-    hipLaunchKernelGGL(k_rescore<T>, dim3(q), dim3(256), 0, stream, bank_bytes, ksteps, static_cast<const T*>(queries),
-                       ldq, d, p.kp, k, index_base, w.carry_r, w.carry_n, out_s, out_i, (int)n, status);
     return isc_launch_status();
 }
 
@@ -988,9 +1165,9 @@ int check_args(int dtype, int64_t n, int d, int q, int k) {
     if (dtype != ISC_F16 && dtype != ISC_F32) return ISC_ERR_INVALID_ARG;
     if (n <= 0 || d <= 0 || q <= 0 || k <= 0 || k > n) return ISC_ERR_INVALID_ARG;
     if (k > ISC_TOPK_MAX_K) return ISC_ERR_UNSUPPORTED;
-    if (n > 0x7fffffff) return ISC_ERR_UNSUPPORTED;  // row ids are int32 inside a shard
-    if (d > 65536) return ISC_ERR_UNSUPPORTED;
-    if (isc_ceil_div(q, 64) > 65535) return ISC_ERR_UNSUPPORTED;
+    if (n > 0x7ffffffe) return ISC_ERR_UNSUPPORTED;  // row ids are int32 inside a shard
+    if (d > ISC_SEARCH_MAX_D) return ISC_ERR_UNSUPPORTED;
+    if (q > ISC_SEARCH_MAX_Q) return ISC_ERR_UNSUPPORTED;
     return ISC_OK;
 }
 
@@ -1000,13 +1177,14 @@ extern "C" int isc_cosine_topk_workspace_bytes(int dtype, int64_t N, int D, int 
     ISC_REQUIRE(bytes);
     const int st = check_args(dtype, N, D, Q, k);
     if (st != ISC_OK) return st;
-    *bytes = carve(make_plan(N, Q, k), isc_ksteps(D, dtype == ISC_F16 ? 2 : 4), nullptr).bytes;
+    *bytes = carve(make_plan(N, Q, k), isc_ksteps(D, dtype == ISC_F16 ? 2 : 4), N, k, nullptr).bytes;
     return ISC_OK;
 }
 
 extern "C" int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, const void* queries, int Q, int64_t ldq,
-                               int k, int64_t index_base, float* out_scores, int64_t* out_indices, int32_t* status,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+                               int k, int64_t index_base, const float* norm_bound, float* out_scores,
+                               int64_t* out_indices, int32_t* status, void* workspace, size_t workspace_bytes,
+                               void* stream) {
     ISC_REQUIRE(bank && queries && out_scores && out_indices && status);
     const int st = check_args(dtype, N, D, Q, k);
     if (st != ISC_OK) return st;
@@ -1016,8 +1194,8 @@ extern "C" int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, co
     isc_cosine_topk_workspace_bytes(dtype, N, D, Q, k, &need);
     if (!workspace || workspace_bytes < need) return ISC_ERR_WORKSPACE;
     if (dtype == ISC_F16)
-        return run<_Float16>(bank, N, D, queries, Q, ldq, k, index_base, out_scores, out_indices, status, workspace,
-                             isc_stream(stream));
-    return run<float>(bank, N, D, queries, Q, ldq, k, index_base, out_scores, out_indices, status, workspace,
-                      isc_stream(stream));
+        return run<_Float16>(bank, N, D, queries, Q, ldq, k, index_base, norm_bound, out_scores, out_indices, status,
+                             workspace, isc_stream(stream));
+    return run<float>(bank, N, D, queries, Q, ldq, k, index_base, norm_bound, out_scores, out_indices, status,
+                      workspace, isc_stream(stream));
 }

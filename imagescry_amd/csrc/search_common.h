@@ -1,0 +1,69 @@
+// Pieces shared by the search kernels (cosine_topk.hip) and the exact float64 search (search_exact.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bank_layout.h"
+
+// ---- (score, row) as one 64-bit key whose unsigned order is the search order ------------------------------------
+// larger key = better candidate: higher score first, then LOWER row.  Keys of distinct rows are distinct.  A NaN
+// score ranks below every number (the oracle's lexsort puts NaN last).  0 is "empty": a real entry has row <=
+// 2^31 - 2, so its low word is >= 1.
+__device__ __forceinline__ unsigned isc_score_bits(float s) {
+    if (s != s) return 0u;
+    unsigned u = __float_as_uint(s);
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;  // monotone float -> unsigned; -inf -> 0x007fffff
+    return u;
+}
+__device__ __forceinline__ unsigned long long isc_make_key(float s, int row) {
+    return ((unsigned long long)isc_score_bits(s) << 32) | (unsigned)(0x7fffffff - row);
+}
+__device__ __forceinline__ float isc_key_score(unsigned long long k) {
+    unsigned u = (unsigned)(k >> 32);
+    if (u == 0u) return __uint_as_float(0x7fc00000u);  // NaN
+    u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ int isc_key_row(unsigned long long k) {
+    return 0x7fffffff - (int)(unsigned)(k & 0xffffffffu);
+}
+__device__ __forceinline__ unsigned long long isc_bcast_key(unsigned long long k, int src_lane) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)k, src_lane);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(k >> 32), src_lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long isc_wave_max_key(unsigned long long k) {
+    unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned olo = __shfl_xor(lo, off, 64), ohi = __shfl_xor(hi, off, 64);
+        const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+        const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+        if (o > m) {
+            lo = olo;
+            hi = ohi;
+        }
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// ---- exact float64 search of a LIST of queries (search_exact.hip) -------------------------------------------------
+// Workspace of k_exact: the device-side list of queries to search (filled by k_final, or with every query by
+// isc_cosine_topk_exhaustive), one sorted partial list of k keys per (listed query, chunk of bank tiles), and the
+// arrival counter of the last-workgroup merge.
+struct IscExactWs {
+    int32_t* redo_count;       // [1]  number of listed queries
+    int32_t* redo_list;        // [q]  their indices (into this pass's queries)
+    int32_t* done;             // [1]  workgroups that have published their partial lists
+    unsigned long long* part;  // [q][chunks][k]  keys (exact float32 score, ORIGINAL row), best first
+    int chunks;                // workgroups of k_exact
+    int tiles_per_chunk;
+};
+size_t isc_exact_ws_bytes(int64_t n, int q, int k);
+IscExactWs isc_exact_ws_carve(void* base, int64_t n, int q, int k);
+// enqueue k_exact: searches queries redo_list[0 .. *redo_count) and writes rows redo_list[i] of out_s / out_i
+// (leading dimension k).  `q_stride_rows` queries of `dtype` at `queries` with leading dimension ldq.
+int isc_exact_launch(int dtype, const void* bank, int64_t n, int d, const void* queries, int64_t ldq, int k,
+                     int64_t index_base, const IscExactWs& ws, float* out_s, int64_t* out_i, int32_t* status,
+                     hipStream_t stream);

@@ -781,6 +781,7 @@ extern "C" int isc_gemm_f16(const void* a, int64_t M, int K, const void* w, int 
     if (big) {
         const long long tiles2 = isc_ceil_div<long long>(M, 256) * isc_ceil_div<long long>(N, 256);
         const long long grid2 = isc_ceil_div<long long>(tiles2, 8) * 8;  // gemm_tile: 8 equal slices, one per XCD
+#ifdef ISC_ABLATION  // wrong-result bring-up variants: -DISC_ABLATION builds only
         static const int dbg = [] {
             const char* e = getenv("ISC_GEMM_DEBUG");
             return e ? atoi(e) : 0;
@@ -788,20 +789,23 @@ extern "C" int isc_gemm_f16(const void* a, int64_t M, int K, const void* w, int 
         if (dbg == 1) hipLaunchKernelGGL(k_gemm_f16_big<1>, dim3((unsigned)grid2), dim3(256), 0, s, p);
         else if (dbg == 2) hipLaunchKernelGGL(k_gemm_f16_big<2>, dim3((unsigned)grid2), dim3(256), 0, s, p);
         else if (dbg == 3) hipLaunchKernelGGL(k_gemm_f16_big<3>, dim3((unsigned)grid2), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(k_gemm_f16_big<0>, dim3((unsigned)grid2), dim3(256), 0, s, p);
+        else
+#endif
+            hipLaunchKernelGGL(k_gemm_f16_big<0>, dim3((unsigned)grid2), dim3(256), 0, s, p);
     } else {
         const long long grid1 = isc_ceil_div<long long>(tiles, 8) * 8;
-        {
-            static const int dbg1 = [] {
-                const char* e = getenv("ISC_GEMM_DEBUG");
-                return e ? atoi(e) : 0;
-            }();
-            if (dbg1 == 1) hipLaunchKernelGGL(k_gemm_f16_dma<1>, dim3((unsigned)grid1), dim3(256), 0, s, p);
-            else if (dbg1 == 2) hipLaunchKernelGGL(k_gemm_f16_dma<2>, dim3((unsigned)grid1), dim3(256), 0, s, p);
-            else if (dbg1 == 3) hipLaunchKernelGGL(k_gemm_f16_dma<3>, dim3((unsigned)grid1), dim3(256), 0, s, p);
-            else if (dbg1 == 4) hipLaunchKernelGGL(k_gemm_f16_dma<4>, dim3((unsigned)grid1), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL(k_gemm_f16_dma<0>, dim3((unsigned)grid1), dim3(256), 0, s, p);
-        }
+#ifdef ISC_ABLATION
+        static const int dbg1 = [] {
+            const char* e = getenv("ISC_GEMM_DEBUG");
+            return e ? atoi(e) : 0;
+        }();
+        if (dbg1 == 1) hipLaunchKernelGGL(k_gemm_f16_dma<1>, dim3((unsigned)grid1), dim3(256), 0, s, p);
+        else if (dbg1 == 2) hipLaunchKernelGGL(k_gemm_f16_dma<2>, dim3((unsigned)grid1), dim3(256), 0, s, p);
+        else if (dbg1 == 3) hipLaunchKernelGGL(k_gemm_f16_dma<3>, dim3((unsigned)grid1), dim3(256), 0, s, p);
+        else if (dbg1 == 4) hipLaunchKernelGGL(k_gemm_f16_dma<4>, dim3((unsigned)grid1), dim3(256), 0, s, p);
+        else
+#endif
+            hipLaunchKernelGGL(k_gemm_f16_dma<0>, dim3((unsigned)grid1), dim3(256), 0, s, p);
     }
     isc_timing_end(ISC_KERNEL_GEMM_F16, s);
     return isc_launch_status();

@@ -98,9 +98,9 @@ class EmbedSearchPipeline:
     by `EmbeddingBank.search`; each rank returns the rows of its own batch.  All ranks must feed the same number of
     batches with the same number of embedding rows.
 
-    Ordering between the two streams is by events only; the host never waits inside the loop.  Candidate-buffer
-    overflow words are collected and checked once at the end; an affected batch is searched again with the checked
-    path (`EmbeddingBank.search(check=True)`).
+    Ordering between the two streams is by events only; the host never waits inside the loop, and there is nothing to
+    check afterwards: `EmbeddingBank.search` is final on the device (queries the float32 filter cannot prove are redone
+    exactly by the same call).
     """
 
     def __init__(self, *, embedding_model: EmbeddingModule, bank: EmbeddingBank, k: int = 10, overlap: bool = True) -> None:
@@ -141,7 +141,7 @@ class EmbedSearchPipeline:
             enc_stream, search_stream = torch.cuda.Stream(device), torch.cuda.Stream(device)
             enc_stream.wait_stream(torch.cuda.current_stream(device))
             search_stream.wait_stream(torch.cuda.current_stream(device))
-        pending: list[tuple[Tensor, int, Tensor, Tensor, Tensor, Tensor | None]] = []
+        pending: list[tuple[Tensor, int, Tensor, Tensor]] = []
         for batch in dataloader:
             batch = batch.to(device)
             if use_streams:
@@ -156,29 +156,18 @@ class EmbedSearchPipeline:
                 with torch.cuda.stream(search_stream):
                     search_stream.wait_event(ready)
                     q.record_stream(search_stream)
-                    scores, neighbours = self.bank.search(q, self.k, check=False)
-                    status = self.bank.last_status
+                    scores, neighbours = self.bank.search(q, self.k)
             else:
                 emb = self.embedding_model.predict_step(batch)
                 q = self._queries(emb)
                 rows = emb.get_flat_vectors().shape[0]
-                scores, neighbours = self.bank.search(q, self.k, check=False)
-                status = self.bank.last_status
-            pending.append((batch.indices, rows, q, scores, neighbours, status))
+                scores, neighbours = self.bank.search(q, self.k)
+            pending.append((batch.indices, rows, scores, neighbours))
         if use_streams:
             torch.cuda.current_stream(device).wait_stream(enc_stream)
             torch.cuda.current_stream(device).wait_stream(search_stream)
         results = []
-        for indices, rows, q, scores, neighbours, status in pending:
-            overflowed = status is not None and int(status[0].item()) != 0
-            if self.bank.process_group is not None:  # every rank must take the same branch: agree on the flag
-                group = self.bank.process_group
-                flag = torch.tensor([int(overflowed)], dtype=torch.int32,
-                                    device="cpu" if dist.get_backend(group) == "gloo" else device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-                overflowed = bool(flag.item())
-            if overflowed:
-                scores, neighbours = self.bank.search(q, self.k, check=True)
+        for indices, rows, scores, neighbours in pending:
             results.append(SearchResult(indices=indices, scores=self._own_rows(scores, rows),
                                         neighbours=self._own_rows(neighbours, rows)))
         return results

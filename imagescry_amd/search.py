@@ -11,6 +11,12 @@ time with the `F.normalize` formula of src/imagescry/models/embedding.py:74), re
 (score descending, row index ascending).  Row ids are positions in the bank, the analogue of the reference's
 DB row order (operations.py:135-144).
 
+The matrix-core pass is a float32 filter; the candidates are re-scored in float64, a rounding-error guard proves per
+query that the filter lost nothing, and what it cannot prove is searched again exactly on the device -- one call, no
+host synchronisation, the result is final (csrc/cosine_topk.hip).  The bank is stored in a fixed pseudo-random row
+order (`isc_bank_permutation`), so banks whose rows arrive sorted or clustered -- the reference's store returns all
+cells of one image adjacent, operations.py:135-144 -- behave like shuffled ones; indices are always original rows.
+
 Multi-GPU: one process per GPU.  The bank is row-sharded -- rank r holds rows `[r*N//G, (r+1)*N//G)` -- every
 rank searches its shard with the replicated queries, one all-gather (RCCL over xGMI) exchanges the
 `Q x k x 12 B` partial results and every rank merges them; the merge order is total, so the answer does not
@@ -129,11 +135,14 @@ class EmbeddingBank:
 
     def _store(self, embeddings: Tensor, normalize: bool) -> Tensor:
         """Row-normalise / cast the rows and write them into the PACKED bank image (`isc_bank_pack`):
-        `[tile of 256 rows][K step][row][128 B]`, the layout the search kernels stream (include/imagescry_hip.h)."""
+        `[tile of 256 rows][K step][row][128 B]`, rows permuted, the layout the search kernels stream
+        (include/imagescry_hip.h).  `_norm_bound` receives an upper bound of the stored rows' norms (the search's
+        rounding guard needs it)."""
         _lib.require_device(embeddings, "embeddings")
         n, d = embeddings.shape
         lib = _lib.load()
         code = _lib.dtype_code(self.dtype)
+        self._norm_bound = torch.zeros(1, dtype=torch.float32, device=embeddings.device)
         if n == 0:
             return torch.empty(0, dtype=torch.uint8, device=embeddings.device)
         need = _lib.c_size_t()
@@ -150,8 +159,9 @@ class EmbeddingBank:
                 if rows.stride(1) != 1:
                     rows = rows.contiguous()
                 st = lib.isc_bank_pack(
-                    rows.data_ptr(), _lib.dtype_code(rows.dtype), rows.shape[0], d, rows.stride(0), r0,
-                    int(normalize), 1e-12, packed.data_ptr(), code, _lib.stream_handle(embeddings.device),
+                    rows.data_ptr(), _lib.dtype_code(rows.dtype), rows.shape[0], d, rows.stride(0), r0, n,
+                    int(normalize), 1e-12, packed.data_ptr(), code, self._norm_bound.data_ptr(),
+                    _lib.stream_handle(embeddings.device),
                 )
                 _lib.check(st, "isc_bank_pack")
         return packed
@@ -169,8 +179,8 @@ class EmbeddingBank:
             lib = _lib.load()
             with torch.cuda.device(self.device):
                 st = lib.isc_bank_unpack(
-                    self._bank.data_ptr(), _lib.dtype_code(self.dtype), self.dim, 0, self.num_local_rows,
-                    out.data_ptr(), self.dim, _lib.stream_handle(self.device),
+                    self._bank.data_ptr(), _lib.dtype_code(self.dtype), self.dim, self.num_local_rows, 0,
+                    self.num_local_rows, out.data_ptr(), self.dim, _lib.stream_handle(self.device),
                 )
             _lib.check(st, "isc_bank_unpack")
         return out
@@ -203,10 +213,11 @@ class EmbeddingBank:
         return ws
 
     def _local_topk(
-        self, queries: Tensor, k: int, check: bool, out: tuple[Tensor, Tensor, Tensor] | None = None
+        self, queries: Tensor, k: int, out: tuple[Tensor, Tensor, Tensor] | None = None
     ) -> tuple[Tensor, Tensor]:
-        """Top-k of this rank's rows: `(float32 [Q, k], int64 [Q, k])` with GLOBAL row indices.  `out` optionally
-        supplies the (scores, indices, status int32[4]) tensors to write into (the exchange buffer of a sharded search)."""
+        """Top-k of this rank's rows: `(float32 [Q, k], int64 [Q, k])` with GLOBAL row indices, final when the stream
+        has run the call.  `out` optionally supplies the (scores, indices, status int32[4]) tensors to write into (the
+        exchange buffer of a sharded search)."""
         nq = queries.shape[0]
         if out is None:
             scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
@@ -216,23 +227,25 @@ class EmbeddingBank:
             scores, indices, status = out
         ws = self._workspace(nq, k)
         lib = _lib.load()
-        code = _lib.dtype_code(self.dtype)
-        args = (
-            self._bank.data_ptr(), code, self.num_local_rows, self.dim, queries.data_ptr(), nq, queries.stride(0),
-            k, self.index_base, scores.data_ptr(), indices.data_ptr(),
-        )
         with torch.cuda.device(self.device):
-            stream = _lib.stream_handle(self.device)
-            st = lib.isc_cosine_topk(*args, status.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+            st = lib.isc_cosine_topk(
+                self._bank.data_ptr(), _lib.dtype_code(self.dtype), self.num_local_rows, self.dim, queries.data_ptr(),
+                nq, queries.stride(0), k, self.index_base, self._norm_bound.data_ptr(), scores.data_ptr(),
+                indices.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_handle(self.device),
+            )
             _lib.check(st, "isc_cosine_topk")
-            self.last_status = status
-            if check and int(status[0].item()) != 0:
-                self._exhaustive(args, nq, k, stream)
+        self.last_status = status
         return scores, indices
 
-    def _exhaustive(self, args: tuple, nq: int, k: int, stream: int) -> None:
-        """A candidate buffer overflowed (adversarially ordered or heavily duplicated bank): redo the call with the
-        data-independent float64 kernel, into the same output tensors."""
+    def search_exhaustive(self, queries: Tensor, k: int = 10) -> tuple[Tensor, Tensor]:
+        """The same answer from the data-independent float64 kernel (`isc_cosine_topk_exhaustive`): every score of
+        every query evaluated exactly.  Slow; the on-device reference the fast path is tested against."""
+        q = self._prepare_queries(queries)
+        nq = q.shape[0]
+        if self.process_group is not None:
+            raise ValueError("search_exhaustive answers for one shard; merge the shards with search()")
+        if not 1 <= k <= self.num_local_rows:
+            raise ValueError(f"k={k} must be in [1, {self.num_local_rows}]")
         lib = _lib.load()
         code = _lib.dtype_code(self.dtype)
         need = _lib.c_size_t()
@@ -241,8 +254,16 @@ class EmbeddingBank:
             "isc_cosine_topk_exhaustive_workspace_bytes",
         )
         ews = torch.empty(need.value, dtype=torch.uint8, device=self.device)
-        st = lib.isc_cosine_topk_exhaustive(*args, ews.data_ptr(), ews.numel(), stream)
+        scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        indices = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            st = lib.isc_cosine_topk_exhaustive(
+                self._bank.data_ptr(), code, self.num_local_rows, self.dim, q.data_ptr(), nq, q.stride(0), k,
+                self.index_base, scores.data_ptr(), indices.data_ptr(), ews.data_ptr(), ews.numel(),
+                _lib.stream_handle(self.device),
+            )
         _lib.check(st, "isc_cosine_topk_exhaustive")
+        return scores, indices
 
     def _merge_topk(self, scores: Tensor, indices: Tensor, k: int) -> tuple[Tensor, Tensor]:
         """Merge `[G, Q, kin]` partial results into `[Q, k]` by (score desc, index asc) (`isc_topk_merge`).  The two
@@ -271,10 +292,13 @@ class EmbeddingBank:
     def search(self, queries: Tensor, k: int = 10, *, check: bool = True) -> tuple[Tensor, Tensor]:
         """Cosine top-k of every query against the whole (possibly sharded) bank.
 
-        Returns `(scores float32 [Q, k], indices int64 [Q, k])`, best first, ties by lower row index.
-        With `check=False` the overflow status word is not read back (no host synchronisation); inspect
-        `last_status[0]` later -- non-zero means the call has to be repeated with `check=True`.
+        Returns `(scores float32 [Q, k], indices int64 [Q, k])`, best first, ties by lower row index.  The call
+        only enqueues work: no host synchronisation, and the result is final -- queries the float32 filter cannot
+        prove are redone exactly on the device.  `last_status` (int32[4], device) holds diagnostics: [0] overflowed
+        candidate buffers, [1] queries answered by the exact pass.  `check` is accepted for compatibility with the
+        first version of this API and ignored.
         """
+        del check
         if not isinstance(k, int) or isinstance(k, bool):
             raise TypeError(f"k must be an int, got {type(k).__name__}")
         if k < 1:
@@ -289,9 +313,10 @@ class EmbeddingBank:
             if nq == 0:
                 return (torch.empty((0, k), dtype=torch.float32, device=self.device),
                         torch.empty((0, k), dtype=torch.int64, device=self.device))
-            return self._local_topk(q, k, check)
+            return self._local_topk(q, k)
 
-        # ---- sharded: local partial top-k -> one all-gather -> merge on every rank
+        # ---- sharded: local partial top-k -> ONE all-gather -> merge on every rank.  Every rank issues exactly one
+        # collective per search whatever its shard holds, so the ranks cannot fall out of step.
         if not hasattr(self, "_n_total"):
             self._n_total = self._total_rows()
         if k > self._n_total:
@@ -314,37 +339,20 @@ class EmbeddingBank:
             part_i.fill_(_PAD_INDEX)
             status.zero_()
             if kl > 0:
-                s, i = self._local_topk(q, kl, check)
+                s, i = self._local_topk(q, kl)
                 part_s[:, :kl] = s
                 part_i[:, :kl] = i
         else:
-            s, i = self._local_topk(q, k, False, out=(part_s, part_i, status))
+            s, i = self._local_topk(q, k, out=(part_s, part_i, status))
             if s.data_ptr() != part_s.data_ptr():  # a test double returned its own tensors
                 part_s.copy_(s)
                 part_i.copy_(i)
                 status.zero_()
-        for attempt in range(2):
-            gathered = self._all_gather_bytes(xbuf)
-            all_s = gathered[:, : 4 * nq * k].view(torch.float32).view(self.world_size, nq, k)
-            all_i = gathered[:, off_i:off_s].view(torch.int64).view(self.world_size, nq, k)
-            result = self._merge_topk(all_s, all_i, k)
-            if not check or attempt == 1 or kl < k:
-                return result
-            flags = gathered[:, off_s : off_s + 4].view(torch.int32).reshape(-1)
-            if not bool((flags != 0).any().item()):  # the one host synchronisation of a checked sharded search
-                return result
-            # some shard's candidate buffers overflowed: those ranks redo their shard exhaustively, then everybody
-            # exchanges and merges again (every rank sees the same flags, so the collective stays matched)
-            if int(status[0].item()) != 0:
-                qq = q
-                args = (
-                    self._bank.data_ptr(), _lib.dtype_code(self.dtype), self.num_local_rows, self.dim, qq.data_ptr(), nq,
-                    qq.stride(0), k, self.index_base, part_s.data_ptr(), part_i.data_ptr(),
-                )
-                with torch.cuda.device(self.device):
-                    self._exhaustive(args, nq, k, _lib.stream_handle(self.device))
-                status.zero_()
-        return result
+        gathered = self._all_gather_bytes(xbuf)
+        all_s = gathered[:, : 4 * nq * k].view(torch.float32).view(self.world_size, nq, k)
+        all_i = gathered[:, off_i:off_s].view(torch.int64).view(self.world_size, nq, k)
+        self.last_gathered_status = gathered[:, off_s:].view(torch.int32)  # [G, 4]: every shard's diagnostics
+        return self._merge_topk(all_s, all_i, k)
 
     def _all_gather_bytes(self, xbuf: Tensor) -> Tensor:
         """`[G, nbytes]` uint8: every rank's exchange buffer (one all-gather; RCCL over xGMI on the GPUs)."""

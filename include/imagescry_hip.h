@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ISC_ABI_VERSION 1
+#define ISC_ABI_VERSION 2
 
 /* element types */
 #define ISC_U8 0
@@ -101,27 +101,34 @@ int isc_resize_bilinear(const void* x, int dtype, int planes, int H1, int W1, in
 int isc_l2norm_channels(const float* x, int B, int E, int S, float eps, float* y, void* stream);
 
 /* Packed bank layout -- how an embedding bank sits in HBM for the search kernels.
- * Rows are grouped in tiles of ISC_BANK_TILE_ROWS; inside a tile the embedding axis is cut into K steps of
- * ISC_BANK_KSTEP_BYTES (64 halves / 32 floats, zero-padded) and stored step-major:
- *     byte offset of (row r, K step s) = ((r / 256 * KS + s) * 256 + r % 256) * 128,   KS = ceil(D * esz / 128)
- * so the 256 x 128 B block one K step of one tile needs is 32 KiB of CONTIGUOUS memory (one coalesced LDS-DMA
- * stream per workgroup, every HBM channel in use) instead of 256 row segments 2*D bytes apart.  The row count is
- * padded to a multiple of 256; the caller zero-fills the padding rows (isc_bank_pack only writes real rows). */
-#define ISC_BANK_TILE_ROWS 256
-#define ISC_BANK_KSTEP_BYTES 128
+ *   rows are grouped in tiles of 256; the embedding axis is cut into K steps of 128 bytes (64 halves / 32 floats,
+ *   zero padded); storage order is [tile][K step][row in tile][128 B], so the block one K step of one tile needs is
+ *   32 KiB of contiguous memory and a workgroup's chunk of tiles is one linear stream.
+ *   ROW ORDER: packed position p holds ORIGINAL row (mul * p) mod N, with mul ~ N / golden ratio coprime to N
+ *   (isc_bank_permutation): every prefix of the packed bank is an even sample of the original rows, so a bank whose
+ *   rows arrive sorted or clustered by similarity -- the reference's store returns all cells of one image adjacent,
+ *   src/imagescry/storage/operations.py:135-144 -- looks exchangeable to the search filter.  Row indices at this API
+ *   are always ORIGINAL rows; the permutation is internal to pack / unpack / search.
+ * The byte size is a multiple of one tile (rows padded to a multiple of 256); the caller zero-fills the padding rows
+ * (isc_bank_pack only writes real rows). */
 int isc_bank_packed_bytes(int dtype, int64_t N, int D, size_t* bytes);
 
-/* Write rows [first_row, first_row + n_rows) of a bank into its packed image, optionally L2-normalising each row
- * first with the formula above (x / max(||x||_2, eps), float32 arithmetic).  `rows` is row-major [n_rows, D] of
- * `in_dtype` (ISC_F16 or ISC_F32, leading dimension ldx); `packed` holds `dtype` (ISC_F16 or ISC_F32).
+/* host: the row permutation of an N-row bank (orig = mul * p mod N, p = mul_inv * orig mod N); N < 2^31 */
+int isc_bank_permutation(int64_t N, int64_t* mul, int64_t* mul_inv);
+
+/* Write rows [first_row, first_row + n_rows) of a bank of `n_total` rows into its packed image, optionally
+ * L2-normalising each row with the `F.normalize(x, p=2, dim=1)` formula x / max(||x||, eps)
+ * (reference src/imagescry/models/embedding.py:74) and casting to the bank dtype.
  * Used once when an embedding bank is built from `EmbeddingBatch.get_flat_vectors()` rows
- * (reference src/imagescry/data.py:112-118). */
-int isc_bank_pack(const void* rows, int in_dtype, int64_t n_rows, int D, int64_t ldx, int64_t first_row, int normalize,
-                  float eps, void* packed, int dtype, void* stream);
+ * (reference src/imagescry/data.py:112-118).
+ *   norm_bound   optional device float, updated with atomic max: an upper bound of the Euclidean norms of the rows AS
+ *                STORED.  Zero it before the first call; isc_cosine_topk's rounding-error guard takes it. */
+int isc_bank_pack(const void* rows, int in_dtype, int64_t n_rows, int D, int64_t ldx, int64_t first_row,
+                  int64_t n_total, int normalize, float eps, void* packed, int dtype, float* norm_bound, void* stream);
 
 /* Inverse of isc_bank_pack for rows [first_row, first_row + n_rows): packed -> row-major [n_rows, D] of `dtype`. */
-int isc_bank_unpack(const void* packed, int dtype, int D, int64_t first_row, int64_t n_rows, void* rows, int64_t ldy,
-                    void* stream);
+int isc_bank_unpack(const void* packed, int dtype, int D, int64_t n_total, int64_t first_row, int64_t n_rows,
+                    void* rows, int64_t ldy, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Encoder blocks (float32, NHWC activations, KRSC weights)
@@ -220,26 +227,35 @@ int isc_vit_assemble(const float* patch_embed, const float* cls_token, const flo
 /* Brute-force cosine top-k of `Q` queries against `N` bank rows.
  * No reference symbol exists; semantics are the oracle's
  * (oracle/search_oracle.py): score = float32(dot_f64(q,b) / max(||q||_2,1e-12)), bank rows used as
- * stored, result ordered by (score descending, row index ascending).
+ * stored, result ordered by (score descending, row index ascending; NaN scores last).
+ * The result is FINAL when the stream has run the call: the matrix-core pass is only a filter, the candidates are
+ * re-scored in float64, a rounding-error guard proves per query that the filter lost nothing, and the queries it cannot
+ * prove (or whose candidate buffers overflowed) are searched again exactly on the device.  No host round trip.
  *   bank         N rows of D values of `dtype` (ISC_F16 or ISC_F32) in the PACKED layout above (isc_bank_pack),
  *                16-byte aligned
  *   queries      row-major [Q, D] of the SAME dtype, leading dimension ldq (elements)
  *   k            1 <= k <= min(N, ISC_TOPK_MAX_K)
  *   index_base   added to every returned row index (global index of this shard's row 0)
+ *   norm_bound   device float: upper bound of the stored rows' norms (isc_bank_pack); NULL = rows are unit length
  *   out_scores   float   [Q, k]
  *   out_indices  int64_t [Q, k]
- *   status       int32_t [4] device words, written by the kernels:
- *                  [0] = number of (segment, query) candidate buffers that overflowed (result then INVALID --
- *                        the host must rerun with isc_cosine_topk_exhaustive), [1..3] reserved
+ *   status       int32_t [4] device words, diagnostics only:
+ *                  [0] = candidate buffers that overflowed, [1] = queries answered by the exact float64 pass,
+ *                  [2] = float bits of max |filter score - exact dot| / guard bound over the re-scored candidates
+ *                        (must stay < 1), [3] reserved
+ * Calls with Q > 1024 run as passes of 1024 queries over the same workspace.  D <= ISC_SEARCH_MAX_D.
  */
 #define ISC_TOPK_MAX_K 120
+#define ISC_SEARCH_MAX_D 8192
+#define ISC_SEARCH_MAX_Q (1 << 24)
 int isc_cosine_topk_workspace_bytes(int dtype, int64_t N, int D, int Q, int k, size_t* bytes);
 int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, const void* queries, int Q, int64_t ldq, int k,
-                    int64_t index_base, float* out_scores, int64_t* out_indices, int32_t* status,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    int64_t index_base, const float* norm_bound, float* out_scores, int64_t* out_indices,
+                    int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Same contract, data-independent cost: every score is evaluated in float64 and kept in a per-query list.
- * Slow (vector FMA, no matrix cores); the fallback for inputs whose candidate buffers overflow. */
+/* Same contract and the same limits, data-independent cost: every score of every query is evaluated in float64
+ * (vector FMA, no matrix cores, about one bank stream per four queries).  The kernel isc_cosine_topk falls back to
+ * per query; exported as the reference implementation of the search on the device. */
 int isc_cosine_topk_exhaustive_workspace_bytes(int dtype, int64_t N, int D, int Q, int k, size_t* bytes);
 int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N, int D, const void* queries, int Q, int64_t ldq,
                                int k, int64_t index_base, float* out_scores, int64_t* out_indices,

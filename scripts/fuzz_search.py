@@ -62,11 +62,16 @@ while time.time() < t_end:
     eb = EmbeddingBank(bank.to(dev), dtype=dtype, normalize=normalize, index_base=base_idx, presharded=base_idx != 0)
     qd = queries.to(dev)
     s, i = eb.search(qd, k)
-    fell = int(eb.last_status[0].item() != 0)
+    st = eb.last_status.cpu().tolist()
+    redone = st[1] - int(zeroq)  # queries answered by the exact pass (a zero query always is: every score ties)
+    fell = int(redone > 0)
     fallbacks += fell
-    by_mode.setdefault(str(mode), [0, 0])
+    by_mode.setdefault(str(mode), [0, 0, 0, 0, 0])
     by_mode[str(mode)][0] += 1
     by_mode[str(mode)][1] += fell
+    by_mode[str(mode)][2] += q
+    by_mode[str(mode)][3] += max(redone, 0)
+    by_mode[str(mode)][4] += int(st[0] != 0)
     if fell and mode == "random" and os.environ.get("FUZZ_VERBOSE"):
         print(f"fallback: n={n} d={d} q={q} k={k} {dtype} normalize={normalize} zeroq={zeroq} status={eb.last_status.tolist()}", flush=True)
     stored = eb.bank.cpu().float().numpy()
@@ -82,6 +87,8 @@ while time.time() < t_end:
         print(f"FAIL n={n} d={d} q={q} k={k} {dtype} mode={mode} normalize={normalize} base={base_idx}: "
               f"{bad} index mismatches, max score diff {diff:.3g}", flush=True)
     del eb
-print("fallbacks by mode (cases, fallbacks):", by_mode, flush=True)
-print(f"{cases} cases, {fails} failures, {fallbacks} took the exhaustive fallback, worst score diff {worst:.3g}", flush=True)
+print("by mode (cases, cases with an exact-pass query, queries, exact-pass queries, cases with an overflowed buffer):", by_mode, flush=True)
+for m, v in by_mode.items():
+    print(f"  {m}: exact-pass query rate {100.0 * v[3] / max(v[2], 1):.3f} %  overflow cases {v[4]} / {v[0]}", flush=True)
+print(f"{cases} cases, {fails} failures, {fallbacks} needed the exact pass for some query, worst score diff {worst:.3g}", flush=True)
 sys.exit(1 if fails else 0)

@@ -42,7 +42,7 @@ def _worker(rank: int, world: int, port: int, n: int, k: int, out_dir: str) -> N
             def _store(self, embeddings, normalize):  # keep the rows on the CPU
                 return embeddings.contiguous()
 
-            def _local_topk(self, queries, kk, check, out=None):  # `out`: the product's exchange buffer (unused here)
+            def _local_topk(self, queries, kk, out=None):  # `out`: the product's exchange buffer (unused here)
                 s, i = search_oracle.cosine_topk(self._bank, queries, kk, index_base=self.index_base)
                 return torch.from_numpy(s), torch.from_numpy(i)
 
@@ -82,6 +82,57 @@ def test_sharded_search_equals_unsharded(world: int, n: int, k: int, tmp_path: P
         np.testing.assert_array_equal(got["scores"], exp_s)
 
 
+def _uneven_worker(rank: int, world: int, port: int, k: int, out_dir: str) -> None:
+    """Presharded, very uneven shards: rank 0 holds 3 rows (fewer than k), rank 1 the rest.  Every rank must issue
+    the same single collective (the first version of this path let the short shard return after one all-gather while
+    a full shard could enter a second one)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cases
+        from imagescry_amd import EmbeddingBank
+        from oracle import search_oracle
+
+        calls = {"gather": 0}
+
+        class OracleBank(EmbeddingBank):
+            def _store(self, embeddings, normalize):
+                return embeddings.contiguous()
+
+            def _local_topk(self, queries, kk, out=None):
+                s, i = search_oracle.cosine_topk(self._bank, queries, kk, index_base=self.index_base)
+                return torch.from_numpy(s), torch.from_numpy(i)
+
+            def _merge_topk(self, scores, indices, kk):
+                s, i = search_oracle.topk_merge(scores.numpy(), indices.numpy(), kk)
+                return torch.from_numpy(s), torch.from_numpy(i)
+
+            def _all_gather_bytes(self, xbuf):
+                calls["gather"] += 1
+                return super()._all_gather_bytes(xbuf)
+
+        n = 3000
+        bank, queries = cases.search_case(n, 32, 6, torch.float16, seed=17)
+        t = torch.linspace(0.0, 1.0, n)[:, None]  # ordered: later rows are closer to query 0
+        bank = torch.nn.functional.normalize(bank.float() * (1 - t) + queries[0].float()[None, :] * t, dim=1).half()
+        lo, hi = (0, 3) if rank == 0 else (3, n)
+        eb = OracleBank(bank[lo:hi], dtype=torch.float16, normalize=False, process_group=dist.group.WORLD,
+                        presharded=True, index_base=lo)
+        for _ in range(2):
+            scores, indices = eb.search(queries, k)
+        assert calls["gather"] == 2  # one collective per search on every rank
+        exp_s, exp_i = search_oracle.cosine_topk(bank, queries, k)
+        np.testing.assert_array_equal(indices.numpy(), exp_i)
+        np.testing.assert_array_equal(scores.numpy(), exp_s)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_uneven_presharded_shards_stay_in_step(tmp_path: Path) -> None:
+    mp.spawn(_uneven_worker, args=(2, _free_port(), 5, str(tmp_path)), nprocs=2, join=True)
+
+
 def _pipeline_worker(rank: int, world: int, port: int, n: int, k: int, out_dir: str) -> None:
     """`EmbedSearchPipeline` over a 2-way sharded bank: each rank 'encodes' its own batches (a test double stands in
     for the HIP embedder: fixed random projection of the mean pixel rows), the embeddings are all-gathered, searched
@@ -98,7 +149,7 @@ def _pipeline_worker(rank: int, world: int, port: int, n: int, k: int, out_dir: 
             def _store(self, embeddings, normalize):
                 return embeddings.contiguous()
 
-            def _local_topk(self, queries, kk, check, out=None):
+            def _local_topk(self, queries, kk, out=None):
                 s, i = search_oracle.cosine_topk(self._bank, queries, kk, index_base=self.index_base)
                 return torch.from_numpy(s), torch.from_numpy(i)
 

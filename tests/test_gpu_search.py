@@ -153,6 +153,20 @@ def test_exhaustive_kernel_matches_oracle(device: torch.device) -> None:
         _check(s, i, exp_s, exp_i)
 
 
+def test_exhaustive_kernel_many_queries_and_wide_rows(device: torch.device) -> None:
+    """k_exact with every query listed: more queries than one pass holds (1024), D = 5000 (one query per sweep),
+    k = 120 (few, long partial lists) -- against the C oracle."""
+    from oracle import c_oracle
+
+    for n, d, q, k, dtype in ((3000, 40, 1100, 3, torch.float16), (700, 5000, 3, 120, torch.float32),
+                              (70000, 200, 9, 10, torch.float16)):
+        bank, queries = cases.search_case(n, d, q, dtype, seed=n)
+        eb = _bank(bank, device)
+        s, i = eb.search_exhaustive(queries.to(device), k)
+        exp_s, exp_i = c_oracle.cosine_topk(bank.float().numpy(), queries.float().numpy(), k)
+        _check(s, i, exp_s, exp_i)
+
+
 def test_packed_bank_round_trip(device: torch.device) -> None:
     """isc_bank_pack -> isc_bank_unpack returns the rows bit for bit (ragged N, D not a multiple of the K step)."""
     for dtype in (torch.float16, torch.float32):
@@ -162,20 +176,139 @@ def test_packed_bank_round_trip(device: torch.device) -> None:
         assert eb._bank.numel() == 5 * (2 if dtype == torch.float16 else 4) * 256 * 128
 
 
-def test_overflow_falls_back_to_exhaustive(device: torch.device) -> None:
-    """A bank sorted by ascending similarity to the query makes every later row beat the threshold: the
-    candidate buffers overflow, status[0] becomes non-zero and `search` reruns on the exhaustive kernel."""
+def test_bank_sorted_by_similarity_stays_on_the_fast_path(device: torch.device) -> None:
+    """A bank sorted by ascending similarity to the query used to make every later row beat the threshold (levels were
+    prefixes of the rows as they arrived): candidate buffers overflowed and the whole call fell back.  The packed bank
+    now stores rows in a pseudo-random order, so the same bank is answered by the fast path."""
     d = 64
     g = cases.gen(11)
     q = torch.nn.functional.normalize(torch.randn(1, d, generator=g), dim=1)
-    noise = torch.nn.functional.normalize(torch.randn(40000, d, generator=g), dim=1)
-    t = torch.linspace(0.0, 0.9, 40000)[:, None]
+    noise = torch.nn.functional.normalize(torch.randn(400000, d, generator=g), dim=1)
+    t = torch.linspace(0.0, 0.9, 400000)[:, None]
     bank = torch.nn.functional.normalize(t * q + (1 - t) * noise * 0.2, dim=1).half()
-    queries = q.half()
-    exp_s, exp_i = search_oracle.cosine_topk(bank, queries, 10)
+    queries = torch.cat([q, torch.randn(70, d, generator=g)]).half()
+    from oracle import c_oracle
+
+    exp_s, exp_i = c_oracle.cosine_topk(bank.float().numpy(), queries.float().numpy(), 10)
     eb = _bank(bank, device)
     scores, indices = eb.search(queries.to(device), 10)
     _check(scores, indices, exp_s, exp_i)
+    st = eb.last_status.cpu().tolist()
+    assert st[0] == 0 and st[1] == 0, st  # no overflow, no query needed the exact pass
+
+
+def test_database_ordered_bank_of_near_duplicate_cells(device: torch.device) -> None:
+    """Rows in the reference's store order (record, h, w) -- src/imagescry/storage/operations.py:135-144,
+    src/imagescry/data.py:112-118: the 49 cells of one 7 x 7 map are adjacent and nearly identical.  Queries are cells of
+    stored images, so ~49 rows crowd the top of every result.  Exact answer, fast path."""
+    from imagescry_amd import EmbeddingBank
+    from oracle import c_oracle
+
+    g = cases.gen(31)
+    images, cells, d = 6000, 49, 96
+    centres = torch.nn.functional.normalize(torch.randn(images, d, generator=g), dim=1)
+    rows = centres[:, None, :] + 0.05 * torch.randn(images, cells, d, generator=g)
+    rows = rows.reshape(images * cells, d)
+    eb = EmbeddingBank(rows.to(device), dtype=torch.float16, normalize=True)
+    stored = eb.bank.cpu()
+    queries = stored[torch.randint(0, images * cells, (96,), generator=g)].float()
+    queries += 0.01 * torch.randn(queries.shape, generator=g)
+    scores, indices = eb.search(queries.to(device), 10)
+    exp_s, exp_i = c_oracle.cosine_topk(stored.float().numpy(), queries.half().float().numpy(), 10)
+    _check(scores, indices, exp_s, exp_i)
+    st = eb.last_status.cpu().tolist()
+    assert st[0] == 0 and st[1] <= 2, st
+
+
+def _ulp_cluster_case(dtype: torch.dtype):
+    """30 rows that differ from each other in the last ulp of a few components, all next to the query: more rows
+    than the filter carries (kp = 16 at k = 10) lie within float32 accumulation noise of the 10th score."""
+    g = cases.gen(41)
+    d, n = 768, 20000
+    bank = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1)
+    q = torch.nn.functional.normalize(torch.randn(1, d, generator=g), dim=1)
+    base = torch.nn.functional.normalize(q + 0.3 * torch.nn.functional.normalize(torch.randn(1, d, generator=g), dim=1), dim=1)
+    base = base.to(dtype)
+    where = torch.randperm(n, generator=g)[:30]
+    for j, r in enumerate(where.tolist()):
+        row = base[0].clone()
+        comp = torch.randint(0, d, (3,), generator=g)
+        bits = row[comp].view(torch.int16 if dtype == torch.float16 else torch.int32)
+        row[comp] = (bits + (1 if j % 2 else -1)).view(dtype)  # one ulp up or down
+        bank[r] = row.float()
+    return bank.to(dtype), torch.cat([q, torch.randn(3, d, generator=g)]).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_rounding_guard_catches_near_duplicates_of_the_kth_neighbour(dtype: torch.dtype, device: torch.device) -> None:
+    """The float32 filter ranks the candidates it carries; rows that differ from the k-th neighbour by one ulp can swap
+    places with it inside float32 accumulation noise.  k_final's guard must notice that it cannot prove the filter's
+    choice and hand the query to the exact pass; the answer is bit-exact either way."""
+    from oracle import c_oracle
+
+    bank, queries = _ulp_cluster_case(dtype)
+    eb = _bank(bank, device)
+    scores, indices = eb.search(queries.to(device), 10)
+    exp_s, exp_i = c_oracle.cosine_topk(bank.float().numpy(), queries.float().numpy(), 10)
+    _check(scores, indices, exp_s, exp_i)
+    st = eb.last_status.cpu()
+    assert int(st[0]) == 0 and int(st[1]) >= 1  # query 0 went through the exact pass
+    ratio = st[2:3].view(torch.float32).item()
+    assert 0.0 < ratio < 0.5, ratio  # observed filter error, in units of the guard's bound
+
+
+def test_guard_bound_holds_for_same_sign_vectors(device: torch.device) -> None:
+    """Worst case for the rounding bound: every product q_i * b_i has the same sign, so the running sum is as large as
+    sum |q_i b_i| all the way.  status[2] reports max |filter score - exact dot| / bound over the re-scored candidates."""
+    g = cases.gen(43)
+    for dtype, d in ((torch.float16, 768), (torch.float16, 4096), (torch.float32, 768)):
+        bank = torch.nn.functional.normalize(torch.rand(30000, d, generator=g) + 0.05, dim=1).to(dtype)
+        queries = (torch.rand(40, d, generator=g) + 0.05).to(dtype)
+        eb = _bank(bank, device)
+        scores, indices = eb.search(queries.to(device), 10)
+        es, ei = eb.search_exhaustive(queries.to(device), 10)
+        assert torch.equal(indices, ei) and torch.equal(scores, es)
+        ratio = eb.last_status.cpu()[2:3].view(torch.float32).item()
+        assert 0.0 <= ratio < 0.5, (dtype, d, ratio)
+
+
+def test_nan_and_inf_queries(device: torch.device) -> None:
+    """A query holding inf (or one that overflows fp16 to inf) scores NaN against every row: the oracle's order puts NaN
+    last, i.e. rows 0..k-1 with NaN scores.  Every output slot is written (the first version left slots 1..k-1 of such
+    a query uninitialised)."""
+    bank, queries = cases.search_case(3000, 64, 5, torch.float16, seed=2)
+    queries = queries.float()
+    queries[1, 3] = float("inf")
+    queries[3, 0] = 1e6  # overflows to inf in fp16
+    queries[4] = float("nan")
+    q16 = queries.half()
+    exp_s, exp_i = search_oracle.cosine_topk(bank, q16, 6)
+    scores, indices = _bank(bank, device).search(queries.to(device), 6)
+    np.testing.assert_array_equal(indices.cpu().numpy(), exp_i)
+    np.testing.assert_allclose(scores.cpu().numpy(), exp_s, rtol=0, atol=SCORE_ATOL, equal_nan=True)
+    for bad in (1, 3, 4):
+        assert indices[bad].cpu().tolist() == list(range(6)) and bool(torch.isnan(scores[bad]).all())
+
+
+def test_sixteen_thousand_queries_in_one_call(device: torch.device) -> None:
+    """EmbedSearchPipeline with a spatial embedder hands over Q = B * h * w queries (12 800 for 32 images at 640 px).
+    Calls with more than 1024 queries run as passes of 1024, so the per-segment candidate load does not grow with Q
+    (with one pass, Q = 16 384 on a 16.7 M-row bank overflowed the 32-slot segments by construction)."""
+    n, d, q, k = 16_700_000, 32, 16384, 10
+    g = torch.Generator(device=device).manual_seed(5)
+    from imagescry_amd import EmbeddingBank
+
+    eb = EmbeddingBank(torch.randn(n, d, generator=g, device=device), dtype=torch.float16, normalize=True)
+    queries = torch.randn(q, d, generator=g, device=device).half()
+    scores, indices = eb.search(queries, k)
+    st = eb.last_status.cpu().tolist()
+    assert st[0] == 0, st
+    assert st[1] <= q // 100, st  # d = 32: scores are coarse, a few near-ties may need the exact pass
+    pick = torch.tensor([0, 1023, 1024, 5000, 16383], device=device)
+    es, ei = eb.search_exhaustive(queries[pick], k)
+    assert torch.equal(indices[pick], ei) and torch.equal(scores[pick], es)
+    s = scores.double()
+    assert bool(((s[:, :-1] > s[:, 1:]) | ((s[:, :-1] == s[:, 1:]) & (indices[:, :-1] < indices[:, 1:]))).all())
 
 
 def test_argument_errors(device: torch.device) -> None:
@@ -191,38 +324,88 @@ def test_argument_errors(device: torch.device) -> None:
         eb.search(queries.to(device).to(torch.int32), 5)
     with pytest.raises(ValueError):
         eb.search(queries, 5)  # CPU queries against a GPU bank
+    from imagescry_amd import EmbeddingBank, _lib
+
+    wide = EmbeddingBank(torch.randn(40, _lib.ISC_SEARCH_MAX_D + 8, device=device), dtype=torch.float16)
+    with pytest.raises(ValueError):  # rejected up front by the fast path, not by its fallback in mid-call
+        wide.search(torch.randn(2, _lib.ISC_SEARCH_MAX_D + 8, device=device), 5)
 
 
-@pytest.mark.parametrize("dtype", [torch.float16])
-def test_full_size_properties(dtype: torch.dtype, device: torch.device) -> None:
-    """BASELINE config 3 shape (1M x 768, 1024 queries, k = 10) checked without a CPU oracle:
-    the expected answer is rebuilt on the GPU with torch float64 matmuls (test-side only)."""
-    n, d, q, k = 1_000_000, 768, 1024, 10
-    g = torch.Generator(device=device).manual_seed(1234)
-    bank = torch.nn.functional.normalize(torch.randn(n, d, generator=g, device=device), dim=1).to(dtype)
-    queries = torch.randn(q, d, generator=g, device=device).to(dtype)
-    from imagescry_amd import EmbeddingBank
-
-    eb = EmbeddingBank(bank, dtype=dtype, normalize=False)
-    scores, indices = eb.search(queries, k)
-    assert int(eb.last_status[0].item()) == 0
-    # sortedness under the total order
+def _assert_topk_properties(bank_rows: torch.Tensor, queries: torch.Tensor, scores: torch.Tensor, indices: torch.Tensor,
+                            k: int, block: int = 65536) -> None:
+    """Size-independent proof that (scores, indices) is THE cosine top-k of `queries` over `bank_rows` (row-major, on the
+    GPU): sorted under the total order; the scores are the exact cosines of the returned rows; no row outside the set
+    beats or ties-with-lower-index the k-th entry.  torch float64 matmuls on the device, test-side only."""
+    n, d = bank_rows.shape
+    q = queries.shape[0]
     s, i = scores.double(), indices
     assert bool(((s[:, :-1] > s[:, 1:]) | ((s[:, :-1] == s[:, 1:]) & (i[:, :-1] < i[:, 1:]))).all())
-    # returned scores are the exact cosine of the returned rows
     q64 = queries.double()
     denom = q64.norm(dim=1).clamp_min(1e-12)
-    rows = bank[indices.reshape(-1)].double().reshape(q, k, d)
+    rows = bank_rows[indices.reshape(-1)].double().reshape(q, k, d)
     exact = (torch.einsum("qkd,qd->qk", rows, q64) / denom[:, None]).float()
     assert torch.allclose(scores, exact, rtol=0, atol=1e-7)
-    # nothing outside the returned set beats the k-th score
     kth = scores[:, -1].double()
-    better = torch.zeros(q, dtype=torch.int64, device=device)
-    for r0 in range(0, n, 65536):
-        blk = (q64 @ bank[r0 : r0 + 65536].double().T / denom[:, None]).float().double()
-        better += (blk > kth[:, None]).sum(dim=1)
-    assert bool((better <= k - 1).all())
-    assert bool((better == (scores.double() > kth[:, None]).sum(dim=1)).all())
+    kth_idx = indices[:, -1]
+    better = torch.zeros(q, dtype=torch.int64, device=scores.device)
+    for r0 in range(0, n, block):
+        blk = (q64 @ bank_rows[r0 : r0 + block].double().T / denom[:, None]).float().double()
+        ridx = torch.arange(r0, r0 + blk.shape[1], device=scores.device)[None, :]
+        better += ((blk > kth[:, None]) | ((blk == kth[:, None]) & (ridx < kth_idx[:, None]))).sum(dim=1)
+    assert bool((better == k - 1).all())
+
+
+def test_full_size_properties_1m(device: torch.device) -> None:
+    """BASELINE config 3 shape (1M x 768, 1024 queries, k = 10) checked without a CPU oracle."""
+    n, d, q, k = 1_000_000, 768, 1024, 10
+    g = torch.Generator(device=device).manual_seed(1234)
+    bank = torch.nn.functional.normalize(torch.randn(n, d, generator=g, device=device), dim=1).half()
+    queries = torch.randn(q, d, generator=g, device=device).half()
+    from imagescry_amd import EmbeddingBank
+
+    eb = EmbeddingBank(bank, dtype=torch.float16, normalize=False)
+    scores, indices = eb.search(queries, k)
+    st = eb.last_status.cpu().tolist()
+    assert st[0] == 0 and st[1] == 0, st
+    _assert_topk_properties(bank, queries, scores, indices, k)
+
+
+def test_full_size_properties_10m_and_eight_shards(device: torch.device) -> None:
+    """BASELINE config 4: the 10 M x 768 fp16 bank of the headline benchmark, at Q = 1024 and Q = 1, proven with the
+    same three properties; then the same bank as eight row shards of 1.25 M rows (the shard of one GPU of the 8-GPU
+    run, index_base != 0), searched one by one and merged with isc_topk_merge: identical to the unsharded answer."""
+    n, d, q, k = 10_000_000, 768, 1024, 10
+    from imagescry_amd import EmbeddingBank, shard_bounds
+
+    g = torch.Generator(device=device).manual_seed(1234)
+    bank = torch.empty((n, d), dtype=torch.float16, device=device)
+    for r0 in range(0, n, 1 << 20):
+        blk = torch.randn((min(1 << 20, n - r0), d), generator=g, device=device)
+        bank[r0 : r0 + blk.shape[0]] = torch.nn.functional.normalize(blk, dim=1).half()
+    queries = torch.randn(q, d, generator=g, device=device).half()
+    eb = EmbeddingBank(bank, dtype=torch.float16, normalize=False)
+    scores, indices = eb.search(queries, k)
+    st = eb.last_status.cpu().tolist()
+    assert st[0] == 0 and st[1] == 0, st
+    _assert_topk_properties(bank, queries, scores, indices, k, block=1 << 18)
+    s1, i1 = eb.search(queries[:1], k)  # the 64-query tile shape (HBM-bound launch)
+    assert torch.equal(i1, indices[:1]) and torch.equal(s1, scores[:1])
+    assert eb.last_status.cpu().tolist()[:2] == [0, 0]
+    del eb
+    torch.cuda.empty_cache()
+    parts_s, parts_i = [], []
+    for r in range(8):
+        lo, hi = shard_bounds(n, 8, r)
+        shard = EmbeddingBank(bank[lo:hi], dtype=torch.float16, normalize=False, index_base=lo, presharded=True)
+        s, i = shard.search(queries, k)
+        assert shard.last_status.cpu().tolist()[:2] == [0, 0]
+        parts_s.append(s)
+        parts_i.append(i)
+        if r == 3:  # one shard also at the HBM-bound shape
+            s16, i16 = shard.search(queries[:16], k)
+            assert torch.equal(i16, i[:16]) and torch.equal(s16, s[:16])
+    ms, mi = shard._merge_topk(torch.stack(parts_s), torch.stack(parts_i), k)
+    assert torch.equal(mi, indices) and torch.equal(ms, scores)
 
 
 def test_bank_from_reference_database(tmp_path, device: torch.device) -> None:
@@ -257,7 +440,7 @@ def test_candidate_counts_just_past_a_multiple_of_512(n: int, device: torch.devi
     scores, indices = eb.search(queries.to(device), 58)
     exp_s, exp_i = c_oracle.cosine_topk(bank.numpy(), queries.numpy(), 58)
     _check(scores, indices, exp_s, exp_i)
-    assert int(eb.last_status[0].item()) == 0
+    assert eb.last_status.cpu().tolist()[:2] == [0, 0]
 
 
 def test_randomised_shapes_against_the_c_oracle(device: torch.device) -> None:
@@ -291,10 +474,10 @@ def test_randomised_shapes_against_the_c_oracle(device: torch.device) -> None:
 
 
 @pytest.mark.parametrize("k,dtype", [(100, torch.float16), (120, torch.float32), (58, torch.float16)])
-def test_large_k_on_a_multi_level_bank_stays_on_the_fast_path(k: int, dtype: torch.dtype, device: torch.device) -> None:
+def test_large_k_on_a_multi_level_bank(k: int, dtype: torch.dtype, device: torch.device) -> None:
     """Regression (scripts/fuzz_search.py deep): with a fixed 64x level growth every search with k > 58 over more than
     4096 rows overflowed the per-query candidate list and silently took the exhaustive kernel.  Also a zero query and
-    duplicated rows (exact ties with the threshold) must not push the call there."""
+    duplicated rows (exact ties with the threshold) must not push the whole call there."""
     from oracle import c_oracle
 
     g = torch.Generator().manual_seed(k)
@@ -307,7 +490,11 @@ def test_large_k_on_a_multi_level_bank_stays_on_the_fast_path(k: int, dtype: tor
 
     eb = EmbeddingBank(bank.to(device), dtype=dtype, normalize=True)
     scores, indices = eb.search(queries.to(device), k)
-    assert int(eb.last_status[0].item()) == 0  # no candidate buffer overflowed
+    st = eb.last_status.cpu().tolist()
+    assert st[0] == 0, st  # no candidate buffer overflowed
+    # the zero query cannot be proven by the filter (every score ties) and goes through the exact pass; duplicated
+    # rows may send a few more there -- never the whole call
+    assert 1 <= st[1] <= q // 4, st
     exp_s, exp_i = c_oracle.cosine_topk(eb.bank.cpu().float().numpy(), queries.to(dtype).float().numpy(), k)
     _check(scores, indices, exp_s, exp_i)
     assert indices[5].cpu().tolist() == list(range(k))  # all-zero query: every score ties at 0, index order
