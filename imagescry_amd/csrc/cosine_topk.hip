@@ -66,8 +66,11 @@ constexpr int SLACK = 6;
 constexpr int SMALL_Q = 128;  // up to this many queries the 64-query tile shape is used
 constexpr int QBATCH = 1024;  // queries per pass: larger calls run as several passes over the same workspace
 constexpr int MAX_LEVELS = 12;
-constexpr int SEL_THREADS = 256;
-constexpr int SURV_CAP = 1024;  // candidates the selection's exact ranking step accepts
+constexpr int SEL_THREADS = 512;
+constexpr int SURV_CAP = 2048;  // candidates the selection's exact ranking step accepts
+constexpr int TAIL_LCAP = 256;                       // k_dots_filter tail: LDS list entries per query (= rows of a tile)
+constexpr int TAIL_COUNT_OFF = 64 * TAIL_LCAP * 8;   // ... byte offsets inside the (by then free) staging LDS
+constexpr int TAIL_LBOUND_OFF = TAIL_COUNT_OFF + 1024;
 
 struct Cand {
     float s;
@@ -289,6 +292,15 @@ __device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned char*
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// ... with the non-temporal cache policy (aux = 2): for bank bytes that exactly one workgroup reads once per search
+template <bool NT>
+__device__ __forceinline__ void glds16_bank(const unsigned char* gsrc, unsigned char* lds_wave_base) {
+    if constexpr (NT)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                         (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+    else
+        glds16(gsrc, lds_wave_base);
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -383,17 +395,20 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     // pipe fed while its partner is held up by the back-pressure of the L2 -> LDS path (+1 % at Q = 1024, +3.5 % at
     // Q = 256; DBG 12 = every wave issues its own share, the A/B reference)
     constexpr bool SPLIT = TNQ == 256 && DBG != 12;
+    // NT: the launch has ONE query tile, so every bank byte is read by exactly one workgroup, once: stream it with the
+    // non-temporal policy (DBG 0 = the single-query-tile form of the 256-query shape, DBG 13 = of the 64-query shape)
+    constexpr bool NT = (TNQ == 256 && DBG == 0) || DBG == 13;
     auto issue_a = [&](int step) {
         const unsigned char* src = a_stream + (int64_t)step * A_TILE_BYTES;
         unsigned char* dst = lds_a + (step % A_ST) * A_TILE_BYTES + wave_dst;
         if constexpr (SPLIT) {
             if (wm == 0) {
 #pragma unroll
-                for (int i = 0; i < 2 * NA; ++i) glds16(src + 4096 * i, dst + 4096 * i);
+                for (int i = 0; i < 2 * NA; ++i) glds16_bank<NT>(src + 4096 * i, dst + 4096 * i);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) glds16(src + 8192 * i, dst + 8192 * i);
+            for (int i = 0; i < NA; ++i) glds16_bank<NT>(src + 8192 * i, dst + 8192 * i);
         }
     };
     auto issue_b = [&](int step) {
@@ -509,14 +524,14 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                     glds16(bsrc + 4096 * (2 * (j_) + 1), bdst + 4096 * (2 * (j_) + 1)); \
                 }                                                                   \
             } else if (do_a) {                                                      \
-                glds16(asrc + 4096 * (2 * ((j_)-4)), adst + 4096 * (2 * ((j_)-4)));  \
-                glds16(asrc + 4096 * (2 * ((j_)-4) + 1), adst + 4096 * (2 * ((j_)-4) + 1)); \
+                glds16_bank<NT>(asrc + 4096 * (2 * ((j_)-4)), adst + 4096 * (2 * ((j_)-4)));  \
+                glds16_bank<NT>(asrc + 4096 * (2 * ((j_)-4) + 1), adst + 4096 * (2 * ((j_)-4) + 1)); \
             }                                                                       \
         }                                                                           \
     } else if ((j_) < 4) {                                                          \
         if (do_b) glds16(bsrc + 8192 * (j_), bdst + 8192 * (j_));                   \
     } else {                                                                        \
-        if (do_a) glds16(asrc + 8192 * ((j_)-4), adst + 8192 * ((j_)-4));           \
+        if (do_a) glds16_bank<NT>(asrc + 8192 * ((j_)-4), adst + 8192 * ((j_)-4));   \
     }
 #define ISC_MFMA_HALF(a_, b_, m_)                                                                         \
     if constexpr (DBG != 3) Mma<T>::half(a_, b_, acc[m_]);                                                 \
@@ -700,6 +715,11 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     if (TNQ == 256 && DBG != 11 && __builtin_amdgcn_readfirstlane(wm) == 1) main_loop(std::true_type{});  // DBG 12 relies on this split
     else main_loop(std::false_type{});
 
+#ifdef ISC_ABLATION  // timing aids (wrong results): nslots bit 16 = stop after the main loop, bit 17 = stop before the tail
+    const int abl = nslots >> 16;
+    nslots &= 0xffff;
+    if (abl & 1) return;
+#endif
     if constexpr (SAMPLE) {
         // ---- level 0 epilogue (one tile per workgroup; every DMA has been retired and every wave is past the last
         // barrier, so the LDS is free).  The 256 scores of a query are cut into `nslots` slots of 256 / nslots scores, each
@@ -717,8 +737,8 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                     for (int n = 0; n < 4; ++n) acc[m][n][r] = -INFINITY;
                 }
         if (nslots > 0) {
-            float* smax = reinterpret_cast<float*>(lds);  // [TNQ][nslots]
-            float* lbound = smax + TNQ * nslots;            // [TNQ]
+            float* smax = reinterpret_cast<float*>(lds);                       // [TNQ][nslots] (<= 128 KiB)
+            float* lbound = reinterpret_cast<float*>(lds + TAIL_LBOUND_OFF);  // [TNQ], past the tail's lists
             const int gsz = TM / nslots;                    // scores per slot: 8, 4 or 2
             const int per_lane = MB * 4 / gsz;              // slots per lane and query column
 #pragma unroll
@@ -735,15 +755,21 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                 }
             }
             __syncthreads();
-            // rank of every slot maximum among its query's nslots (ties by slot index: ranks are a permutation)
+            // rank of every slot maximum among its query's nslots (ties by slot index: ranks are a permutation).  The row
+            // is read 16 bytes at a time, two reads in flight: a scalar loop pays one LDS latency per element.
             for (int id = tid; id < TNQ * nslots; id += NTHREADS) {
                 const int qc = id / nslots, sl = id - qc * nslots;
-                const float* row = smax + (size_t)qc * nslots;
-                const float v = row[sl];
+                const float4* row4 = reinterpret_cast<const float4*>(smax + (size_t)qc * nslots);
+                const float v = smax[(size_t)qc * nslots + sl];
                 int rank = 0;
-                for (int j = 0; j < nslots; ++j) {
-                    const float x = row[j];
-                    rank += (x > v || (x == v && j < sl)) ? 1 : 0;
+#pragma unroll 2
+                for (int j4 = 0; j4 < nslots / 4; ++j4) {
+                    const float4 x = row4[j4];
+                    const int j = j4 * 4;
+                    rank += (x.x > v || (x.x == v && j + 0 < sl)) ? 1 : 0;
+                    rank += (x.y > v || (x.y == v && j + 1 < sl)) ? 1 : 0;
+                    rank += (x.z > v || (x.z == v && j + 2 < sl)) ? 1 : 0;
+                    rank += (x.w > v || (x.w == v && j + 3 < sl)) ? 1 : 0;
                 }
                 if (rank == kp - 1) lbound[qc] = v;
             }
@@ -759,66 +785,100 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                 if (thr[n] != INFINITY) thr[n] = lb == -INFINITY ? -INFINITY : below;
             }
         }
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float s = acc[m][n][r];
-                    if (s > thr[n]) {  // rows past the end are -inf and never pass
-                        const int pos = cnt[n]++;
-                        if (pos < CAP) my_ent[(size_t)n * 16 * CAP + pos] = Cand{s, (int32_t)(trow0 + m * 16 + r)};
-                    }
-                }
     }
 
-    // ---- tail: compact this lane's private survivors into the per-query list.  One returning atomic per
-    // (lane, query block) with survivors, outside the hot loop; the order inside a list is arbitrary, the
-    // selection that follows uses a total order.
+#ifdef ISC_ABLATION
+    if (abl & 2) return;
+#endif
+    // ---- tail: this workgroup's survivors -> the per-query lists, aggregated through LDS so that the list counters see
+    // ONE global atomic per (workgroup, query) (a lane-level atomic per survivor serialises on the counter's address:
+    // 5 k of them on one query's counter took 60 us).  64 queries per pass (the waves of one query column), per query
+    // an LDS list of TAIL_LCAP = 256 entries -- all a tile can produce -- filled with LDS atomics, then copied out by 8
+    // threads per query.  In the filter levels the survivors come from the lane-private segments written in the hot
+    // loop, at level 0 straight from the accumulators.
+    {
+        Cand* lists = reinterpret_cast<Cand*>(lds);                      // [64][TAIL_LCAP]
+        int* lcount = reinterpret_cast<int*>(lds + TAIL_COUNT_OFF);     // [64]
+        const int64_t trow0 = r0 + (int64_t)tile_begin * TM + wm * (TM / WM) + fg * 4;  // level 0: the one tile
+#pragma unroll 1
+        for (int pass = 0; pass < WN; ++pass) {
+            __syncthreads();  // the previous pass has been copied out (first pass: every lane has read its lbound)
+            if (tid < 64) lcount[tid] = 0;
+            __syncthreads();
+            if (wn == pass) {
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int c = min(cnt[n], CAP);
-        const int q = q0 + wn * 64 + n * 16 + frow;
-        if (cnt[n] > CAP) {
-            atomicAdd(&status[0], 1);
-            qflag[q] = 1;
-        }
-        if (c > 0) {
-            const int off = atomicAdd(&qcount[q], c);
-            const Cand* src = my_ent + (size_t)n * 16 * CAP;
-            Cand* dst = qlist + (size_t)q * QCAP;
-            if (off + c > QCAP) {
-                atomicAdd(&status[0], 1);
-                qflag[q] = 1;
+                for (int n = 0; n < 4; ++n) {
+                    const int qc = n * 16 + frow;
+                    if constexpr (SAMPLE) {
+#pragma unroll
+                        for (int m = 0; m < MB; ++m)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float sc = acc[m][n][r];
+                                if (sc > thr[n]) {  // rows past the end are -inf and never pass
+                                    const int pos = atomicAdd(&lcount[qc], 1);
+                                    if (pos < TAIL_LCAP)
+                                        lists[qc * TAIL_LCAP + pos] = Cand{sc, (int32_t)(trow0 + m * 16 + r)};
+                                }
+                            }
+                    } else {
+                        const int c = min(cnt[n], CAP);
+                        if (cnt[n] > CAP) {
+                            atomicAdd(&status[0], 1);
+                            qflag[q0 + wn * 64 + qc] = 1;
+                        }
+                        const Cand* src = my_ent + (size_t)n * 16 * CAP;
+                        for (int i = 0; i < c; i += 4) {  // four independent loads per trip
+                            Cand e[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) e[j] = src[min(i + j, c - 1)];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (i + j < c) {
+                                    const int pos = atomicAdd(&lcount[qc], 1);
+                                    if (pos < TAIL_LCAP) lists[qc * TAIL_LCAP + pos] = e[j];
+                                }
+                        }
+                    }
+                }
             }
-            for (int i = 0; i < c; i += 4) {  // four independent loads per trip
-                Cand e[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = src[min(i + j, c - 1)];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (i + j < c && off + i + j < QCAP) dst[off + i + j] = e[j];
+            __syncthreads();
+            {
+                const int qc = tid >> 3, sub = tid & 7;
+                const int q = q0 + pass * 64 + qc;
+                const int c_all = lcount[qc];
+                const int c = min(c_all, TAIL_LCAP);
+                int off = 0;
+                if (sub == 0 && c > 0) off = atomicAdd(&qcount[q], c);
+                off = __shfl(off, lane & ~7, 64);
+                if (sub == 0 && (c_all > TAIL_LCAP || off + c > QCAP)) {
+                    atomicAdd(&status[0], 1);
+                    qflag[q] = 1;
+                }
+                Cand* dst = qlist + (size_t)q * QCAP + off;
+                for (int i = sub; i < c; i += 8)
+                    if (off + i < QCAP) dst[i] = lists[qc * TAIL_LCAP + i];
             }
         }
     }
 }
 
 // ---- selection ----------------------------------------------------------------------------------------------
-// One WORKGROUP (256 threads) per query: the level's survivors plus the carried list -> the best kp by (score
+// One WORKGROUP (512 threads) per query: the level's survivors plus the carried list -> the best kp by (score
 // desc, packed row asc), written to `topk` (LDS, best first).  Returns how many there are (<= kp), or -1 when the
 // ranking step's buffer would overflow (adversarial list order; the caller marks the query for the exact redo).
 //   1. every thread takes the maximum key of its strided share of the candidates;
-//   2. kp <= 64: per wave, L_w = the kp-th largest of the 64 lane maxima -- at least kp candidates of that wave's
-//      share are >= L_w -- and lim = max over the waves; kp > 64: lim = the kp-th largest of the 256 thread maxima.
+//   2. kp <= 32: per wave, L_w = the kp-th largest of the 64 lane maxima -- at least kp candidates of that wave's
+//      share are >= L_w -- and lim = max over the waves; kp > 32: lim = the kp-th largest of the 512 thread maxima
+//      (at kp = 64 the per-wave form is the MINIMUM lane maximum, which lets a fifth of a long list through).
 //      Either way at least kp candidates are >= lim, so the best kp all are;
 //   3. candidates >= lim (typically ~1.5 kp of them) are compacted into LDS;
 //   4. they are ranked exactly by counting larger keys.
+constexpr int SEL_PER = QCAP / SEL_THREADS;  // list entries per thread: the whole list sits in registers
 struct SelShared {
-    unsigned long long keys[QCAP + ISC_TOPK_MAX_K + 8 + 64];  // candidates of the level + carried list
     unsigned long long surv[SURV_CAP];
     unsigned long long topk[ISC_TOPK_MAX_K + 8];
-    unsigned long long wlim[SEL_THREADS];  // kp <= 64: [0..3] per-wave limits; else the 256 thread maxima
+    unsigned long long wlim[SEL_THREADS];  // kp <= 32: [0..3] per-wave limits; else the thread maxima
     unsigned long long lim;
     int ns;
 };
@@ -829,34 +889,35 @@ __device__ int wg_select(SelShared& sh, int q, int kp, const int32_t* __restrict
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const Cand* src = qlist + (size_t)q * QCAP;
     const int from_list = min(qcount[q], QCAP);
     const int carried = min(carry_n[q], kp);
-    const int total = from_list + carried;
-    const Cand* src = qlist + (size_t)q * QCAP;
     if (tid == 0) sh.ns = 0;
 
-    // 1. keys into LDS, thread maxima on the fly (four independent loads per trip)
+    // 1. every candidate into registers: SEL_PER independent coalesced 8-byte loads per thread, issued BEFORE the
+    // list length is known (the list buffer always holds QCAP slots; what lies past the length is ignored), so the
+    // counter and the list travel in one memory round trip; plus one carried entry (kp <= 128 < 512 threads)
+    unsigned long long key[SEL_PER + 1];
+    {
+        const unsigned long long* raw = reinterpret_cast<const unsigned long long*>(src);
+#pragma unroll
+        for (int j = 0; j < SEL_PER; ++j) key[j] = raw[tid + SEL_THREADS * j];
+        const int ci = min(tid, kp - 1);
+        const float cs = carry_s[(size_t)q * kp + ci];
+        const int cr = carry_r[(size_t)q * kp + ci];
+#pragma unroll
+        for (int j = 0; j < SEL_PER; ++j) {
+            const Cand e{__uint_as_float((unsigned)key[j]), (int)(unsigned)(key[j] >> 32)};
+            key[j] = tid + SEL_THREADS * j < from_list ? isc_make_key(e.s, e.row) : 0ull;
+        }
+        key[SEL_PER] = tid < carried ? isc_make_key(cs, cr) : 0ull;
+    }
     unsigned long long lmax = 0ull;
-    for (int i0 = tid; i0 < from_list; i0 += SEL_THREADS * 4) {
-        Cand e[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = src[min(i0 + SEL_THREADS * j, QCAP - 1)];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i0 + SEL_THREADS * j < from_list) {
-                const unsigned long long key = isc_make_key(e[j].s, e[j].row);
-                sh.keys[i0 + SEL_THREADS * j] = key;
-                lmax = key > lmax ? key : lmax;
-            }
-    }
-    for (int i = tid; i < carried; i += SEL_THREADS) {
-        const unsigned long long key = isc_make_key(carry_s[(size_t)q * kp + i], carry_r[(size_t)q * kp + i]);
-        sh.keys[from_list + i] = key;
-        lmax = key > lmax ? key : lmax;
-    }
+    for (int j = 0; j <= SEL_PER; ++j) lmax = key[j] > lmax ? key[j] : lmax;
 
     // 2. threshold key
-    if (kp <= 64) {
+    if (kp <= 32) {
         int rank = 0;
         for (int j = 0; j < 64; ++j) {
             const unsigned long long o = isc_bcast_key(lmax, j);
@@ -883,19 +944,18 @@ __device__ int wg_select(SelShared& sh, int q, int kp, const int32_t* __restrict
     __syncthreads();
     const unsigned long long lim = sh.lim;
 
-    // 3. compact the candidates >= lim (trip counts are workgroup-uniform: the ballots need every lane)
-    for (int base = 0; base < total; base += SEL_THREADS) {
-        const int i = base + tid;
-        const unsigned long long key = i < total ? sh.keys[i] : 0ull;
-        const bool keep = key != 0ull && key >= lim;
-        const unsigned long long mask = __ballot(keep);
-        int wbase = 0;
-        if (lane == 0 && mask != 0ull) wbase = atomicAdd(&sh.ns, __popcll(mask));
-        wbase = __builtin_amdgcn_readfirstlane(wbase);
-        if (keep) {
-            const int pos = wbase + __popcll(mask & ((1ull << lane) - 1ull));
-            if (pos < SURV_CAP) sh.surv[pos] = key;
-        }
+    // 3. compact the candidates >= lim: one LDS atomic per thread that holds any (typically ~1.5 kp in all)
+    int mine_n = 0;
+#pragma unroll
+    for (int j = 0; j <= SEL_PER; ++j) mine_n += (key[j] != 0ull && key[j] >= lim) ? 1 : 0;
+    if (mine_n > 0) {
+        int pos = atomicAdd(&sh.ns, mine_n);
+#pragma unroll
+        for (int j = 0; j <= SEL_PER; ++j)
+            if (key[j] != 0ull && key[j] >= lim) {
+                if (pos < SURV_CAP) sh.surv[pos] = key[j];
+                ++pos;
+            }
     }
     __syncthreads();
     const int ns = sh.ns;
@@ -905,6 +965,7 @@ __device__ int wg_select(SelShared& sh, int q, int kp, const int32_t* __restrict
     for (int e = tid; e < ns; e += SEL_THREADS) {
         const unsigned long long mine = sh.surv[e];
         int rank = 0;
+#pragma unroll 8
         for (int j = 0; j < ns; ++j) rank += sh.surv[j] > mine ? 1 : 0;
         if (rank < kp) sh.topk[rank] = mine;
     }
@@ -913,7 +974,7 @@ __device__ int wg_select(SelShared& sh, int q, int kp, const int32_t* __restrict
 }
 
 // between two levels: carried list and tau of every query
-__global__ __launch_bounds__(SEL_THREADS) void k_select(int32_t* __restrict__ qcount, const Cand* __restrict__ qlist,
+__global__ __launch_bounds__(SEL_THREADS, 4) void k_select(int32_t* __restrict__ qcount, const Cand* __restrict__ qlist,
                                                         int kp, float* __restrict__ tau, float* __restrict__ carry_s,
                                                         int32_t* __restrict__ carry_r, int32_t* __restrict__ carry_n,
                                                         int32_t* __restrict__ qflag) {
@@ -971,7 +1032,7 @@ struct Chunk16<float> {
 // One workgroup per query: last selection, exact float64 re-score of the carried candidates, final order, output,
 // and the guard that proves the float32 filter lost nothing (see the file header).
 template <typename T>
-__global__ __launch_bounds__(SEL_THREADS) void k_final(
+__global__ __launch_bounds__(SEL_THREADS, 4) void k_final(
     const unsigned char* __restrict__ bank, int ks, const unsigned char* __restrict__ qpacked, int tnq, int kp, int k,
     IscPerm pm, int64_t index_base, const float* __restrict__ norm_bound, const int32_t* __restrict__ qcount,
     const Cand* __restrict__ qlist, const float* __restrict__ carry_s, const int32_t* __restrict__ carry_r,
@@ -1010,24 +1071,38 @@ __global__ __launch_bounds__(SEL_THREADS) void k_final(
         acc = isc_wave_sum(acc);
         if (lane == 0) qnorm_sh = sqrt(acc);
     }
-    // exact dots: one wave per candidate, a lane covers the 16-byte chunk `ch` of K steps sub, sub + 8, ...
-    for (int c = wave; c < nc; c += SEL_THREADS / 64) {
-        const int row = isc_key_row(sh.topk[c]);
-        double acc = 0.0;
-        if ((unsigned)row < (unsigned)pm.n) {
-            for (int s0 = 0; s0 < ks; s0 += 8) {
-                const int s = s0 + sub;
-                if (s < ks) {
-                    double a[8], b[8];
-                    Chunk16<T>::load(bank + isc_packed_offset(row, s, ks) + ch * 16, a);
-                    Chunk16<T>::load(qrow_base + (size_t)s * tnq * ISC_KSTEP_BYTES + ch * 16, b);
+    // exact dots: one wave per candidate, a lane covers the 16-byte chunk `ch` of K steps sub, sub + 8, ...; four
+    // candidates of a wave are in flight together (their loads are independent)
+    constexpr int NW = SEL_THREADS / 64;
+    for (int c0 = wave; c0 < nc; c0 += 4 * NW) {
+        int row[4];
+        double acc[4];
 #pragma unroll
-                    for (int j = 0; j < Chunk16<T>::N; ++j) acc = fma(a[j], b[j], acc);
-                }
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * NW;
+            row[u] = c < nc ? isc_key_row(sh.topk[c]) : -1;
+            if ((unsigned)row[u] >= (unsigned)pm.n) row[u] = -1;
+            acc[u] = 0.0;
+        }
+        for (int s0 = 0; s0 < ks; s0 += 8) {
+            const int s = s0 + sub;
+            if (s < ks) {
+                double a[4][8], b[8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    Chunk16<T>::load(bank + isc_packed_offset(row[u] < 0 ? 0 : row[u], s, ks) + ch * 16, a[u]);
+                Chunk16<T>::load(qrow_base + (size_t)s * tnq * ISC_KSTEP_BYTES + ch * 16, b);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < Chunk16<T>::N; ++j) acc[u] = fma(a[u][j], b[j], acc[u]);
             }
         }
-        acc = isc_wave_sum(acc);
-        if (lane == 0) exact_dot[c] = acc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double tot = isc_wave_sum(acc[u]);
+            if (lane == 0 && c0 + u * NW < nc) exact_dot[c0 + u * NW] = row[u] < 0 ? 0.0 : tot;
+        }
     }
     __syncthreads();
     const double qnorm = qnorm_sh;
@@ -1090,6 +1165,15 @@ int debug_mode() {
 constexpr int debug_mode() { return 0; }
 #endif
 
+#ifdef ISC_ABLATION
+bool no_nt() {
+    static const bool v = getenv("ISC_NO_NT") != nullptr;  // A/B aid: default cache policy on every bank stream
+    return v;
+}
+#else
+constexpr bool no_nt() { return false; }
+#endif
+
 template <typename T, int TNQ>
 void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsigned char* bank, int ksteps,
                    int32_t* status, hipStream_t stream) {
@@ -1098,7 +1182,24 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
                        bank, l.r0, l.r1, l.tiles_per_chunk, l.ntiles, w.qpacked, ksteps, w.tau, p.qpad, w.seg_ent,   \
                        w.qcount, w.qlist, p.kp, p.nslots, w.qflag, status)
     if (l.sample) {  // one tile per workgroup: the staging variant does not matter
-        ISC_LAUNCH_FILTER(12, true);
+#ifdef ISC_ABLATION
+        static const int abl = [] {
+            const char* e = getenv("ISC_SAMPLE_ABL");
+            return e ? atoi(e) : 0;
+        }();
+        Plan pa = p;
+        pa.nslots |= abl << 16;
+        hipLaunchKernelGGL((k_dots_filter<T, TNQ, 12, true>), dim3(l.nchunks, p.qtiles), dim3(NTHREADS), 0, stream, bank,
+                           l.r0, l.r1, l.tiles_per_chunk, l.ntiles, w.qpacked, ksteps, w.tau, p.qpad, w.seg_ent, w.qcount,
+                           w.qlist, p.kp, pa.nslots, w.qflag, status);
+#else
+        if constexpr (TNQ == 64) {
+            if (p.qtiles == 1) ISC_LAUNCH_FILTER(13, true);  // one query tile: non-temporal bank stream
+            else ISC_LAUNCH_FILTER(12, true);
+        } else {
+            ISC_LAUNCH_FILTER(12, true);
+        }
+#endif
         return;
     }
     // SPLIT (DBG 0) pays where a chunk has ONE query tile (Q <= 256).  With several query-tile workgroups streaming the
@@ -1118,8 +1219,12 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
 #endif
         case 12: ISC_LAUNCH_FILTER(12, false); break;
         default:
-            if constexpr (TNQ == 256) ISC_LAUNCH_FILTER(0, false);
-            else ISC_LAUNCH_FILTER(12, false);  // the 64-query shape has no SPLIT: one instantiation
+            if constexpr (TNQ == 256) {
+                ISC_LAUNCH_FILTER(0, false);
+            } else {  // the 64-query shape has no SPLIT; one query tile -> non-temporal bank stream (13)
+                if (p.qtiles == 1 && !no_nt()) ISC_LAUNCH_FILTER(13, false);
+                else ISC_LAUNCH_FILTER(12, false);
+            }
             break;
     }
 #undef ISC_LAUNCH_FILTER

@@ -72,7 +72,7 @@ while time.time() < t_end:
     by_mode[str(mode)][2] += q
     by_mode[str(mode)][3] += max(redone, 0)
     by_mode[str(mode)][4] += int(st[0] != 0)
-    if fell and mode == "random" and os.environ.get("FUZZ_VERBOSE"):
+    if (fell or st[0]) and mode == "random" and os.environ.get("FUZZ_VERBOSE"):
         print(f"fallback: n={n} d={d} q={q} k={k} {dtype} normalize={normalize} zeroq={zeroq} status={eb.last_status.tolist()}", flush=True)
     stored = eb.bank.cpu().float().numpy()
     qcast = queries.to(dtype).float().numpy()

@@ -18,13 +18,13 @@ for n, q in cases:
     eb = EmbeddingBank(bank, dtype=torch.float16, normalize=False)
     del bank
     for _ in range(2):
-        eb.search(queries, 10, check=False)
+        eb.search(queries, 10)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     iters = 5
     e0.record()
     for _ in range(iters):
-        eb.search(queries, 10, check=False)
+        eb.search(queries, 10)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters

