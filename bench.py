@@ -210,6 +210,19 @@ def measured_encode_traffic(batch: int) -> tuple[float | None, str | None]:
     return None, None
 
 
+def measured_vit_traffic(batch: int) -> tuple[float | None, str | None, float | None]:
+    """L2 <-> fabric bytes per `k_gemm_f16` launch of the ViT-B/16 step from the newest committed PMC summary
+    (profiles/*_vit_traffic.json, scripts/pmc_gemm.sh): average over the four GEMM shapes of an encoder layer."""
+    for f in sorted((ROOT / "profiles").glob("*_vit_traffic.json"), reverse=True):
+        try:
+            t = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if t.get("config", {}).get("batch_per_gpu") == batch:
+            return float(t["hbm_bytes_per_launch"]), f"profiles/{f.name}", t.get("traffic_over_algorithmic")
+    return None, None, None
+
+
 def search_roofline(rows: int, d: int, q: int, k: int, kernel_ms_per_step: float, launches_per_step: float) -> dict:
     """Roofline entry of k_dots_filter for one search step on one rank.  Algorithmic work:
     every local bank row is read once (2 B / element) and dotted with every query."""
@@ -444,6 +457,7 @@ def bench_encode_vit(args: argparse.Namespace, device: torch.device, steps: int,
     gemm_flops = float(b) * (2 * (t - 1) * d * 3 * cfg.patch_size**2
                              + cfg.depth * (2 * t * d * 3 * d + 2 * t * d * d + 4 * t * d * cfg.mlp_dim))
     tflops = gemm_flops * steps / (kernel_ms / 1e3) / 1e12
+    vit_traffic, vit_traffic_src, vit_ratio = measured_vit_traffic(b)
     return {
         "metric": "images/s encode",
         "value": round(b * steps / seconds, 1),
@@ -459,7 +473,9 @@ def bench_encode_vit(args: argparse.Namespace, device: torch.device, steps: int,
             "peak": MFMA_F16_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(tflops / MFMA_F16_PEAK_TFLOPS, 4),
-            "traffic": None,
+            "traffic": vit_traffic,
+            "traffic_source": vit_traffic_src,
+            "traffic_over_algorithmic": vit_ratio,
             "launches_per_step": launches / steps,
             "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
             "kernel_ms_per_step": round(kernel_ms / steps, 3),

@@ -26,7 +26,7 @@ ISC_ACT_RESIDUAL_AFTER = 0x100
 ISC_TOPK_MAX_K = 120
 ISC_SEARCH_MAX_D = 8192
 ISC_ABI_VERSION = 2
-ISC_GEMM_A_PACKED, ISC_GEMM_W_PACKED, ISC_GEMM_OUT_PACKED, ISC_GEMM_TILE_256 = 1, 2, 4, 8
+ISC_GEMM_A_PACKED, ISC_GEMM_W_PACKED, ISC_GEMM_OUT_PACKED, ISC_GEMM_TILE_256, ISC_GEMM_TILE_128 = 1, 2, 4, 8, 16
 ISC_KERNEL_DOTS_FILTER, ISC_KERNEL_CONV, ISC_KERNEL_GEMM_F16 = 0, 1, 2
 
 ISC_OK = 0

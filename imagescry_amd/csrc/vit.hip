@@ -734,6 +734,11 @@ __global__ __launch_bounds__(256) void k_vit_assemble(const float* __restrict__ 
     }
 }
 
+}  // namespace
+int isc_gemm_f16_stream_launch(const void* a, long long M, int K, const void* w, int N, const float* bias,
+                               const float* residual, int epi, void* out, int out_packed, hipStream_t stream);
+namespace {
+
 int grid_for(size_t work_items) {
     const size_t blocks = isc_ceil_div<size_t>(work_items, 256);
     return (int)(blocks < 16384 ? (blocks ? blocks : 1) : 16384);
@@ -746,12 +751,25 @@ extern "C" int isc_gemm_f16(const void* a, int64_t M, int K, const void* w, int 
     ISC_REQUIRE(a && w && out && M > 0 && K > 0 && N > 0);
     ISC_REQUIRE(act == ISC_ACT_NONE || act == ISC_ACT_GELU);
     ISC_REQUIRE(out_dtype == ISC_F16 || out_dtype == ISC_F32);
-    ISC_REQUIRE((flags & ~(ISC_GEMM_A_PACKED | ISC_GEMM_W_PACKED | ISC_GEMM_OUT_PACKED | ISC_GEMM_TILE_256)) == 0);
+    ISC_REQUIRE((flags & ~(ISC_GEMM_A_PACKED | ISC_GEMM_W_PACKED | ISC_GEMM_OUT_PACKED | ISC_GEMM_TILE_256 |
+                           ISC_GEMM_TILE_128)) == 0);
     if (K % 64 != 0 || N % 4 != 0) return ISC_ERR_UNSUPPORTED;
     if ((flags & ISC_GEMM_OUT_PACKED) && (out_dtype != ISC_F16 || N % 64 != 0)) return ISC_ERR_UNSUPPORTED;
     if (!isc_aligned(a, 16) || !isc_aligned(w, 16) || !isc_aligned(out, 16) || (bias && !isc_aligned(bias, 16)) ||
         (residual && !isc_aligned(residual, 16)))
         return ISC_ERR_ALIGNMENT;
+    // Packed operands and a multiple of 256 output features (every GEMM of the ViT encoder): the streaming kernel of
+    // gemm_stream.hip -- 256 x 256 tiles on the search kernel's LDS-DMA ring loop.  ISC_GEMM_TILE_128 / _256 select the
+    // older kernels below explicitly.
+    if ((flags & ISC_GEMM_A_PACKED) && (flags & ISC_GEMM_W_PACKED) && !(flags & (ISC_GEMM_TILE_128 | ISC_GEMM_TILE_256)) &&
+        N % 256 == 0 && !(out_dtype == ISC_F32 && act != ISC_ACT_NONE) && !(out_dtype == ISC_F16 && residual)) {
+        const int epi = out_dtype == ISC_F32 ? 2 : act == ISC_ACT_GELU ? 1 : 0;
+        isc_timing_begin(ISC_KERNEL_GEMM_F16, isc_stream(stream));
+        const int st = isc_gemm_f16_stream_launch(a, M, K, w, N, bias, residual, epi, out,
+                                                  (flags & ISC_GEMM_OUT_PACKED) != 0, isc_stream(stream));
+        isc_timing_end(ISC_KERNEL_GEMM_F16, isc_stream(stream));
+        return st;
+    }
     GemmParams p;
     p.a = reinterpret_cast<const _Float16*>(a);
     p.w = reinterpret_cast<const _Float16*>(w);

@@ -192,6 +192,8 @@ int isc_global_avgpool_nhwc(const float* x, int B, int H, int W, int C, float* y
 #define ISC_GEMM_OUT_PACKED 4 /* `out` (fp16 only, N % 64 == 0) is written packed */
 #define ISC_GEMM_TILE_256 8   /* use the 256 x 256-tile kernel (one wave per SIMD, LDS-DMA rings); needs K >= 192,
                                  act == ISC_ACT_NONE and operands below 4 GiB, else ISC_ERR_UNSUPPORTED */
+#define ISC_GEMM_TILE_128 16  /* use the 128 x 128-tile kernel even where the streaming kernel applies (packed a and w,
+                                 N % 256 == 0: 256 x 256 tiles on the search kernel's LDS-DMA ring loop, the default) */
 
 /* out[M,N] = act(a[M,K] . w[N,K]^T + bias[N]) + residual[M,N].   a, w fp16, row-major (w in torch.nn.Linear layout)
  * or packed per `flags`; bias, residual float32 row-major (either may be NULL); act ISC_ACT_NONE or ISC_ACT_GELU

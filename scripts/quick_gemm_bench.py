@@ -21,6 +21,8 @@ for name, k, n, act, res in (("qkv", 768, 2304, 0, False), ("proj", 768, 768, 0,
     flags = (3 | (0 if res else 4)) if pk else 0
     if os.environ.get("GEMM_TILE") == "256" and act == 0:
         flags |= 8
+    if os.environ.get("GEMM_TILE") == "128":
+        flags |= 16
     s = _lib.stream_handle(dev)
     def run():
         _lib.check(lib.isc_gemm_f16(a.data_ptr(), m, k, w.data_ptr(), n, b.data_ptr(), _lib.ptr(r), act, out.data_ptr(),

@@ -22,7 +22,7 @@ def _gen(seed: int) -> torch.Generator:
     return torch.Generator().manual_seed(seed)
 
 
-@pytest.mark.parametrize("layout", ["rowmajor", "packed", "packed-tile256", "rowmajor-tile256"])
+@pytest.mark.parametrize("layout", ["rowmajor", "packed", "packed-tile128", "packed-tile256", "rowmajor-tile256"])
 @pytest.mark.parametrize(
     "m,k,n,act,res,out_f32",
     [
@@ -35,6 +35,8 @@ def _gen(seed: int) -> torch.Generator:
         (2100, 768, 768, "none", True, True),  # several tiles, ragged last one
         (2304, 3072, 772, "none", True, True),  # 48 K steps, ragged feature tile
         (2049, 192, 2304, "none", False, False),  # 3 K steps (the minimum of the 256-tile kernel), fp16 output
+        (5000, 64, 512, "gelu", False, False),  # ONE K step per tile on the streaming kernel, several tiles per chunk
+        (70000, 128, 256, "none", True, True),  # 274 token tiles x one feature block: chunks of two tiles
     ],
 )
 def test_gemm_f16(device, m, k, n, act, res, out_f32, layout):
@@ -65,6 +67,8 @@ def test_gemm_f16(device, m, k, n, act, res, out_f32, layout):
         flags = _lib.ISC_GEMM_A_PACKED | _lib.ISC_GEMM_W_PACKED | (0 if out_f32 else _lib.ISC_GEMM_OUT_PACKED)
     if tile256:
         flags |= _lib.ISC_GEMM_TILE_256
+    if layout.endswith("tile128"):  # "packed" alone takes the streaming kernel wherever N % 256 == 0
+        flags |= _lib.ISC_GEMM_TILE_128
     n_out = packed_elems(m, n) if pk and not out_f32 else m * n
     out = torch.full((n_out,), float("nan"), dtype=torch.float32 if out_f32 else torch.float16, device=device)
     st = _lib.load().isc_gemm_f16(ad.data_ptr(), m, k, wd.data_ptr(), n, bd.data_ptr(), _lib.ptr(rd),
@@ -97,7 +101,7 @@ def test_gemm_f16_rejects_bad_arguments(device):
         _lib.ISC_ERR_INVALID_ARG
     assert lib.isc_gemm_f16(a.data_ptr(), 8, 64, w.data_ptr(), 8, None, None, 0, out.data_ptr(), _lib.ISC_F32,
                             _lib.ISC_GEMM_OUT_PACKED, s) == _lib.ISC_ERR_UNSUPPORTED  # packed output is fp16 only
-    assert lib.isc_gemm_f16(a.data_ptr(), 8, 64, w.data_ptr(), 8, None, None, 0, out.data_ptr(), _lib.ISC_F32, 16, s) == \
+    assert lib.isc_gemm_f16(a.data_ptr(), 8, 64, w.data_ptr(), 8, None, None, 0, out.data_ptr(), _lib.ISC_F32, 32, s) == \
         _lib.ISC_ERR_INVALID_ARG  # unknown flag
     assert lib.isc_gemm_f16(a.data_ptr(), 8, 64, w.data_ptr(), 8, None, None, 0, out.data_ptr(), _lib.ISC_F32,
                             _lib.ISC_GEMM_TILE_256, s) == _lib.ISC_ERR_UNSUPPORTED  # one K step only
