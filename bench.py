@@ -38,7 +38,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 from imagescry_amd import (  # noqa: E402
-    EmbeddingBank, ImageBatch, ResNet50Embedder, ViTB16Embedder, _lib, resnet50, shard_bounds, vit,
+    EfficientNetEmbedder, EmbeddingBank, ImageBatch, ResNet50Embedder, ViTB16Embedder, _lib, efficientnet, resnet50,
+    shard_bounds, vit,
 )
 
 SEED = 1234
@@ -484,6 +485,50 @@ def bench_encode_vit(args: argparse.Namespace, device: torch.device, steps: int,
     }
 
 
+def bench_encode_efficientnet(args: argparse.Namespace, device: torch.device, steps: int, warmup: int) -> dict:
+    """The reference's own embedder (src/imagescry/models/embedding.py:108-183): EfficientNetV2-S features, float32,
+    batch 512 at 224 x 224 -> [512, 1280, 7, 7] per-cell embeddings."""
+    b = args.batch
+    model = EfficientNetEmbedder(backbone_size="s", seed=0).to(device)
+    images = torch.randint(0, 256, (b, 3, 224, 224), dtype=torch.uint8,
+                           generator=torch.Generator().manual_seed(SEED)).to(device)
+    batch = ImageBatch(indices=torch.arange(b, device=device), images=images)
+    for _ in range(warmup):
+        model.predict_step(batch)
+    _lib.timing_enable(True)
+    _lib.timing_read(_lib.ISC_KERNEL_CONV)
+    seconds = timed_steps(lambda: model.predict_step(batch), steps, 0, 1, device)
+    kernel_ms, launches = _lib.timing_read(_lib.ISC_KERNEL_CONV)
+    _lib.timing_enable(False)
+    flops = float(efficientnet.conv_flops("s", b, 224, 224))
+    tflops = flops * steps / (kernel_ms / 1e3) / 1e12
+    return {
+        "metric": "images/s encode",
+        "value": round(b * steps / seconds, 1),
+        "unit": "images/s",
+        "ms_per_step": round(seconds / steps * 1e3, 3),
+        "dtype": "f32",
+        "config": {"workload": f"EfficientNetV2-S (random weights, the reference's embedder) batch-{b} 224x224 uint8 -> "
+                               f"[B,1280,7,7] predict_step, fp32", "batch_per_gpu": b, "parallelism": "replicas1"},
+        "roofline": {
+            "kernel": "k_conv_f32",
+            "bound": "mfma",
+            "achieved": round(tflops, 2),
+            "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "launches_per_step": launches / steps,
+            "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
+            "kernel_ms_per_step": round(kernel_ms / steps, 3),
+            "algorithmic_flops_per_step": flops,
+            "note": "algorithmic FLOPs use the true channel counts; the kernel pads channel counts to multiples of 32 "
+                    "(24 -> 32, 48 -> 64 in the first stages) and so executes more; depthwise convolutions and the "
+                    "squeeze-excitation pooling (not matrix-core work) take the rest of the step",
+        },
+    }
+
+
 def bench_pipeline(args: argparse.Namespace, rank: int, world: int, device: torch.device) -> dict:
     """BASELINE.json configs[4]: ViT-B/16 fp16 encode of 512-image batches pipelined into a row-sharded
     50 M x 768 fp16 search, encode and search on two HIP streams.  A step = every rank encodes one batch of 512 and all
@@ -562,18 +607,20 @@ def main() -> None:
         primary = bench_search(args, rank, world, device)
         primary.pop("_bank"), primary.pop("_queries")
         torch.cuda.empty_cache()
-        secondary = secondary_vit = None
+        secondary = secondary_vit = secondary_eff = None
         if not args.no_secondary and rank == 0:
             secondary = bench_encode(args, rank, world, device, steps=3, warmup=1, collective_timing=False)
             secondary.pop("_model"), secondary.pop("_images")
             torch.cuda.empty_cache()
             secondary_vit = bench_encode_vit(args, device, steps=3, warmup=1)
+            torch.cuda.empty_cache()
+            secondary_eff = bench_encode_efficientnet(args, device, steps=3, warmup=1)
     elif args.workload == "pipeline":
         primary = bench_pipeline(args, rank, world, device)
-        secondary = secondary_vit = None
+        secondary = secondary_vit = secondary_eff = None
     else:
         primary = bench_encode(args, rank, world, device, args.steps, args.warmup, collective_timing=True)
-        secondary = secondary_vit = None
+        secondary = secondary_vit = secondary_eff = None
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -609,6 +656,8 @@ def main() -> None:
             line["encode"] = enc
         if secondary_vit is not None:
             line["encode_vit_b16"] = secondary_vit
+        if secondary_eff is not None:
+            line["encode_efficientnet_v2_s"] = secondary_eff
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -102,6 +102,34 @@ def block_specs(size: str) -> list[list[BlockSpec]]:
     return stages
 
 
+def conv_flops(size: str, batch: int, height: int, width: int) -> int:
+    """Multiply-add FLOPs (2 per MAC) of the DENSE convolutions of one forward pass (stem, expand / fused / project /
+    squeeze-excitation / head convolutions -- the launches of `k_conv_f32`), from the stage table with the true channel
+    counts (no padding); depthwise convolutions are not matrix-core work and are left out.  For the MFMA roofline."""
+    def down(n: int, s: int) -> int:
+        return (n + s - 1) // s
+
+    h, w = down(height, 2), down(width, 2)
+    total = 2 * batch * h * w * STAGES[size][0][4] * 3 * 9  # stem 3x3 / 2
+    last = STAGES[size][0][4]
+    for blocks in block_specs(size):
+        for b in blocks:
+            h2, w2 = down(h, b.stride), down(w, b.stride)
+            k2 = b.kernel * b.kernel
+            if b.kind == "fused":
+                if b.expand == 1:
+                    total += 2 * batch * h2 * w2 * b.cout * b.cin * k2
+                else:
+                    total += 2 * batch * h2 * w2 * b.expanded * b.cin * k2 + 2 * batch * h2 * w2 * b.cout * b.expanded
+            else:
+                total += 2 * batch * h * w * b.expanded * b.cin  # expand 1x1 (input resolution)
+                total += 2 * 2 * batch * b.expanded * b.squeeze  # squeeze-excitation fc1 + fc2
+                total += 2 * batch * h2 * w2 * b.cout * b.expanded  # project
+            h, w, last = h2, w2, b.cout
+    total += 2 * batch * h * w * LAST_CHANNELS * last  # head 1x1
+    return total
+
+
 # ------------------------------------------------------------------------------------------- parameters
 def make_state_dict(size: str = "s", *, seed: int = 0, randomize_bn: bool = False) -> dict[str, Tensor]:
     """Seeded random parameters with torchvision's names and init (conv: kaiming-normal fan_out; BatchNorm identity,
