@@ -1174,6 +1174,19 @@ bool no_nt() {
 constexpr bool no_nt() { return false; }
 #endif
 
+// tiles per chunk and launch above which a level with several query tiles is cut into more launches
+#ifdef ISC_ABLATION
+int seg_tiles() {
+    static const int v = [] {
+        const char* e = getenv("ISC_SEG_TILES");
+        return e ? atoi(e) : 128;
+    }();
+    return v;
+}
+#else
+constexpr int seg_tiles() { return 128; }
+#endif
+
 template <typename T, int TNQ>
 void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsigned char* bank, int ksteps,
                    int32_t* status, hipStream_t stream) {
@@ -1248,10 +1261,28 @@ int run(const void* bank, int64_t n, int d, const void* queries, int q_total, in
                            w.exact.redo_count, w.exact.done, status, q0 == 0 ? 1 : 0);
         for (int li = 0; li < p.nlevels; ++li) {
             const Level& l = p.levels[li];
-            isc_timing_begin(ISC_KERNEL_DOTS_FILTER, stream);
-            if (p.tnq == 256) launch_filter<T, 256>(l, p, w, bank_bytes, ksteps, status, stream);
-            else launch_filter<T, 64>(l, p, w, bank_bytes, ksteps, status, stream);
-            isc_timing_end(ISC_KERNEL_DOTS_FILTER, stream);
+            // With several query-tile workgroups per chunk, a long level runs as several launches over consecutive row
+            // ranges (same thresholds, no selection in between): the partner workgroups that share a chunk's bank rows
+            // through their XCD's L2 drift apart as a launch goes on, and a kernel boundary realigns them for free
+            // (measured L2 -> fabric reads per search: 1.9 x the algorithmic bytes with 594 tiles per chunk and launch,
+            // 1.3 x with 127 / 483).
+            int nseg = 1;
+            if (!l.sample && p.qtiles > 1) nseg = isc_ceil_div(l.tiles_per_chunk, seg_tiles());
+            const int64_t seg_rows = isc_ceil_div<int64_t>(isc_ceil_div<int64_t>(l.r1 - l.r0, nseg), TM) * TM;
+            for (int sg = 0; sg < nseg; ++sg) {
+                Level ls = l;
+                ls.r0 = l.r0 + sg * seg_rows;
+                ls.r1 = ls.r0 + seg_rows < l.r1 ? ls.r0 + seg_rows : l.r1;
+                if (ls.r0 >= ls.r1) break;
+                ls.ntiles = (int)isc_ceil_div<int64_t>(ls.r1 - ls.r0, TM);
+                int want = l.nchunks < ls.ntiles ? l.nchunks : ls.ntiles;
+                ls.tiles_per_chunk = isc_ceil_div(ls.ntiles, want);
+                ls.nchunks = isc_ceil_div(ls.ntiles, ls.tiles_per_chunk);
+                isc_timing_begin(ISC_KERNEL_DOTS_FILTER, stream);
+                if (p.tnq == 256) launch_filter<T, 256>(ls, p, w, bank_bytes, ksteps, status, stream);
+                else launch_filter<T, 64>(ls, p, w, bank_bytes, ksteps, status, stream);
+                isc_timing_end(ISC_KERNEL_DOTS_FILTER, stream);
+            }
             if (li + 1 < p.nlevels)
                 hipLaunchKernelGGL(k_select, dim3(q), dim3(SEL_THREADS), 0, stream, w.qcount, w.qlist, p.kp, w.tau,
                                    w.carry_s, w.carry_r, w.carry_n, w.qflag);
