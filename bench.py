@@ -183,7 +183,7 @@ def selfcheck(shard: torch.Tensor, lo: int, queries: torch.Tensor, scores: torch
     return out
 
 
-def measured_traffic(config: dict) -> tuple[float | None, str | None]:
+def measured_traffic(config: dict) -> tuple[float | None, str | None, bool]:
     """HBM bytes per `k_dots_filter` launch from the newest committed PMC summary whose workload equals `config`
     (profiles/*_headline_traffic.json, written by scripts/summarize_headline_traffic.py from separate rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE passes; counters cannot be read from inside this process)."""
@@ -194,8 +194,9 @@ def measured_traffic(config: dict) -> tuple[float | None, str | None]:
         except (OSError, ValueError):
             continue
         if all(t.get("config", {}).get(k) == config.get(k) for k in keys):
-            return float(t["hbm_bytes_per_launch"]), f"profiles/{f.name}"
-    return None, None
+            # per STEP when the summary has it (the number of launches per step is a tuning knob), else per launch
+            return float(t.get("hbm_bytes_per_step", t["hbm_bytes_per_launch"])), f"profiles/{f.name}", "hbm_bytes_per_step" in t
+    return None, None, False
 
 
 def measured_encode_traffic(batch: int) -> tuple[float | None, str | None]:
@@ -331,12 +332,14 @@ def bench_search(args: argparse.Namespace, rank: int, world: int, device: torch.
             torch.cuda.empty_cache()
             sweep += query_sweep(small, shard_rows, d, k, device, qs=(1, 16, 64, 1024))
             del small
-    traffic, traffic_src = measured_traffic({"bank_rows": n, "dim": d, "queries": q, "k": k, "rows_per_gpu": rows})
-    roofline["traffic"] = traffic
+    traffic, traffic_src, per_step = measured_traffic({"bank_rows": n, "dim": d, "queries": q, "k": k, "rows_per_gpu": rows})
     if traffic_src:
+        lps = max(roofline["launches_per_step"], 1e-9)
+        step_bytes = traffic if per_step else traffic * lps
+        roofline["traffic"] = step_bytes / lps  # per launch, like `achieved`
+        roofline["traffic_per_step"] = step_bytes
         roofline["traffic_source"] = traffic_src
-        roofline["traffic_over_algorithmic"] = round(
-            traffic / (roofline["algorithmic_bytes_per_step"] / max(roofline["launches_per_step"], 1e-9)), 3)
+        roofline["traffic_over_algorithmic"] = round(step_bytes / roofline["algorithmic_bytes_per_step"], 3)
     return {
         "metric": "queries/s cosine top-10 over N x D bank",
         "value": round(q * args.steps / seconds, 1),

@@ -36,7 +36,8 @@ write, n_w = total("write", "WRITE_SIZE")
 assert n_f == n_w and n_f > 0
 read_b = fetch * 1024 * 2 / n_f
 write_b = write * 1024 / n_w
-algo = bench["roofline"]["algorithmic_bytes_per_step"] / bench["roofline"]["launches_per_step"]
+lps = bench["roofline"]["launches_per_step"]
+algo = bench["roofline"]["algorithmic_bytes_per_step"] / lps
 out = {
     "tag": tag,
     "config": bench["config"],
@@ -46,6 +47,9 @@ out = {
     "hbm_write_bytes_per_launch": write_b,
     "hbm_bytes_per_launch": read_b + write_b,
     "algorithmic_bytes_per_launch": algo,
+    "launches_per_step": lps,
+    "hbm_bytes_per_step": (read_b + write_b) * lps,
+    "algorithmic_bytes_per_step": algo * lps,
     "ratio_to_algorithmic": (read_b + write_b) / algo,
     "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), x1024 B, FETCH_SIZE x2 (gfx950)",
 }
