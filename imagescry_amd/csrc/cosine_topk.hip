@@ -473,6 +473,19 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     const int seg = (chunk * WM + wm) * 4 + fg;
     Cand* my_ent = seg_ent + ((size_t)seg * qpad + q0 + wn * 64 + frow) * CAP;  // + n * 16 * CAP
 
+    // Static priority for the second-dispatched half of the workgroup (waves 4 - 7, the wm = 1 partners of every SIMD in
+    // the 256-query shape): that half loses the SIMD's issue arbitration to the older half on every segment
+    // (MI355X_MICROARCH.md, "Two waves per SIMD" item 4); one s_setprio before the loop, no flips inside.  +1.0 % at
+    // Q = 1024 (scripts/ab_headline.sh, three interleaved rounds: 13.71 -> 13.57 ms); per-cluster flips lost 5 % in round 1.
+    // The condition must be provably wave-uniform: s_setprio is a scalar instruction that ignores EXEC.
+    // Not with SPLIT (DBG 0: only the older half issues the LDS-DMA there, and prioritising the other half on top of
+    // that cost 4 %).
+    if constexpr (TNQ == 256 && DBG == 12) {
+#ifdef ISC_ABLATION
+        if (!((nslots >> 18) & 1))
+#endif
+            if (__builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
+    }
     // prologue: what iterations -DA .. -1 would have issued; then publish step 0
     for (int it = -DA; it < 0; ++it) issue_iter(it);
     retire_for(0);
@@ -1193,7 +1206,8 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
 #define ISC_LAUNCH_FILTER(DBG_, SAMPLE_)                                                                             \
     hipLaunchKernelGGL((k_dots_filter<T, TNQ, DBG_, SAMPLE_>), dim3(l.nchunks, p.qtiles), dim3(NTHREADS), 0, stream, \
                        bank, l.r0, l.r1, l.tiles_per_chunk, l.ntiles, w.qpacked, ksteps, w.tau, p.qpad, w.seg_ent,   \
-                       w.qcount, w.qlist, p.kp, p.nslots, w.qflag, status)
+                       w.qcount, w.qlist, p.kp, nslots_arg, w.qflag, status)
+    int nslots_arg = p.nslots;
     if (l.sample) {  // one tile per workgroup: the staging variant does not matter
 #ifdef ISC_ABLATION
         static const int abl = [] {
@@ -1220,7 +1234,14 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
     // (measured L2 -> fabric reads per search at Q = 1024: 3.0 x the algorithmic bytes with SPLIT, 1.6 - 2.0 x without,
     // for +1 % speed), so those launches use the every-wave-issues form (DBG 12).
     int mode = debug_mode();
+#ifdef ISC_ABLATION
+    static const bool force_split = getenv("ISC_FORCE_SPLIT") != nullptr;
+    static const int prio = getenv("ISC_NO_STATIC_PRIO") ? 1 : 0;  // A/B aid: bit 18 of nslots switches the priority off
+    nslots_arg |= prio << 18;
+    if (mode == 0 && TNQ == 256 && p.qtiles > 1 && !force_split) mode = 12;
+#else
     if (mode == 0 && TNQ == 256 && p.qtiles > 1) mode = 12;
+#endif
     switch (mode) {
 #ifdef ISC_ABLATION
         case 2: ISC_LAUNCH_FILTER(2, false); break;

@@ -198,6 +198,9 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // static priority for the second-dispatched half of the workgroup, as in k_dots_filter
+    if (__builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
+
     for (int it = -DA; it < 0; ++it) issue_iter(it);
     retire_for(0);
     __builtin_amdgcn_s_barrier();
