@@ -14,6 +14,8 @@
 // residual are 16-byte loads.  LDS tiles are [rows][128 B] with the 16-byte chunks XOR-swizzled by (row >> 1) & 7
 // (conflict-free ds_read_b128 fragment reads), double buffered, one barrier per K step, next step prefetched
 // into registers while the current one is on the matrix cores.
+#include <stdlib.h>
+
 #include "isc_common.h"
 
 namespace {
@@ -349,6 +351,17 @@ int stream_grid(size_t items) {
 
 }  // namespace
 
+int isc_conv1x1_stream_launch(const float* x, long long M, int K, const float* w, int N, const float* bias,
+                              const float* residual, int act, int res_after_act, float* out, hipStream_t stream);
+#ifdef ISC_ABLATION
+static bool conv_no_stream() {
+    static const bool v = getenv("ISC_CONV_NO_STREAM") != nullptr;  // A/B aid
+    return v;
+}
+#else
+static constexpr bool conv_no_stream() { return false; }
+#endif
+
 static int conv_launch(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S, int stride,
                        int pad, const float* bias, const float* residual, const float* sub, const float* scale, int act,
                        float* out, void* stream) {
@@ -377,6 +390,18 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = tap4 ? 1 : Cin / 32; p.ksteps = ksteps; p.act = act; p.res_after_act = res_after_act;
     hipStream_t s = isc_stream(stream);
+    // 1 x 1, stride 1, whole 256-channel output blocks, a residual, at most four K steps, enough pixel tiles to fill the
+    // chip (ResNet-50 layer1 / layer2 expand convolutions): the streaming kernel of conv1x1_stream.hip, +6 % there.
+    // Measured per layer (scripts/trace_encode_layers.sh): 1088 vs 1170 us (K = 64), 769 vs 820 us (K = 128); from
+    // K = 256 on and without a residual the implicit-GEMM kernel below is as fast or faster, so it keeps those.
+    if (R == 1 && S == 1 && stride == 1 && pad == 0 && !tap4 && !sub && !scale && Cout % 256 == 0 && residual && Cin <= 128 &&
+        (act == ISC_ACT_NONE || act == ISC_ACT_RELU || act == ISC_ACT_SILU) && !conv_no_stream() &&
+        isc_ceil_div<int64_t>(M, 256) * (Cout / 256) >= 512) {
+        isc_timing_begin(ISC_KERNEL_CONV, s);
+        const int st = isc_conv1x1_stream_launch(x, M, Cin, w, Cout, bias, residual, act, res_after_act, out, s);
+        isc_timing_end(ISC_KERNEL_CONV, s);
+        return st;
+    }
     const bool narrow = Cout <= 64;
     const int64_t blocks = narrow ? isc_ceil_div(Cout, 64) * isc_ceil_div<int64_t>(M, 256)
                                   : isc_ceil_div(Cout, 128) * isc_ceil_div<int64_t>(M, 128);

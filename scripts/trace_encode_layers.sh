@@ -1,0 +1,47 @@
+#!/bin/bash
+# per-layer time / TFLOP/s / GB/s of the ResNet-50 encode step (rocprofv3 kernel trace of scripts/trace_encode.py,
+# k_conv_f32 launches matched in order with the layer table)
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+rm -rf gpurun_out/prof_enc
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_enc -- python3 scripts/trace_encode.py > gpurun_out/prof_enc.log 2>&1
+python3 - <<'PY'
+import csv, glob
+B = 512
+layers = []  # (name, pixels_out, cin*k*k, cout, in_bytes, out_bytes, res_bytes)
+def out(n, k, s, p): return (n + 2 * p - k) // s + 1
+h = w = out(224, 7, 2, 3)
+layers.append(("stem 7x7/2", B * h * w, 49 * 4, 64, B * 224 * 224 * 16, B * h * w * 64 * 4, 0))
+h = w = out(h, 3, 2, 1)
+inpl = 64
+for li, (planes, nb, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)), 1):
+    for bi in range(nb):
+        s = stride if bi == 0 else 1
+        h2 = out(h, 3, s, 1)
+        px_in, px_out = B * h * h, B * h2 * h2
+        if bi == 0:
+            layers.append((f"l{li}.{bi}.down 1x1/{s}", px_out, inpl, planes * 4, px_in * inpl * 4, px_out * planes * 16, 0))
+        layers.append((f"l{li}.{bi}.conv1 1x1", px_in, inpl, planes, px_in * inpl * 4, px_in * planes * 4, 0))
+        layers.append((f"l{li}.{bi}.conv2 3x3/{s}", px_out, planes * 9, planes, px_in * planes * 4, px_out * planes * 4, 0))
+        layers.append((f"l{li}.{bi}.conv3 1x1+res", px_out, planes, planes * 4, px_out * planes * 4, px_out * planes * 16, px_out * planes * 16))
+        inpl = planes * 4
+        h = h2
+layers.append(("fc 2048->768", B, 2048, 768, B * 2048 * 4, B * 768 * 4, 0))
+f = glob.glob("gpurun_out/prof_enc/*/*kernel_trace.csv")[0]
+rows = [r for r in csv.DictReader(open(f)) if "k_conv_f32" in r["Kernel_Name"] or "k_conv1x1_f32_stream" in r["Kernel_Name"]]
+n = len(layers)
+last = rows[-n:]
+tot_t = tot_f = 0
+print(f"{'layer':22s} {'M':>9s} {'K':>5s} {'N':>5s} {'us':>8s} {'TFLOP/s':>8s} {'of peak':>7s} {'GB/s':>7s}  tile")
+agg = {}
+for (name, m, k, nn, ib, ob, rb), r in zip(layers, last):
+    us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    fl = 2.0 * m * k * nn
+    tot_t += us; tot_f += fl
+    tile = ("stream " if "stream" in r["Kernel_Name"] else "") + r["Kernel_Name"].split("<")[1].split(">")[0]
+    print(f"{name:22s} {m:9d} {k:5d} {nn:5d} {us:8.1f} {fl/us/1e6:8.1f} {fl/us/1e6/157.3:7.2f} {(ib+ob+rb)/us/1e3:7.0f}  {tile}")
+    kind = name.split(".")[-1].split(" ")[0] if name.startswith("l") else name.split(" ")[0]
+    a = agg.setdefault(name[:2] + " " + kind, [0, 0]); a[0] += us; a[1] += fl
+print(f"total conv {tot_t:.0f} us, {tot_f/tot_t/1e6:.1f} TFLOP/s = {tot_f/tot_t/1e6/157.3:.3f} of the f32 MFMA peak")
+for k2, (us, fl) in agg.items():
+    print(f"  {k2:12s} {us:8.0f} us  {fl/us/1e6:6.1f} TFLOP/s")
+PY

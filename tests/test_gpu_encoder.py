@@ -39,6 +39,10 @@ def _rel_err(got: torch.Tensor, exp: torch.Tensor) -> float:
         (5, 1, 1, 2048, 768, 1, 1, 0),  # the projection head as a 1x1 conv
         (1, 7, 7, 160, 64, 1, 1, 0),  # stem GEMM over im2col rows
         (1, 10, 10, 32, 100, 5, 1, 2),  # Cout not a tile multiple, 5x5
+        # large enough for the streaming 1 x 1 kernel (conv1x1_stream.hip): ragged last pixel tile, 1 / 2 / 4 channel blocks
+        (8, 130, 130, 64, 256, 1, 1, 0),  # ResNet layer1 expand: two K steps per tile
+        (4, 129, 129, 256, 512, 1, 1, 0),
+        (2, 200, 200, 32, 1024, 1, 1, 0),  # ONE K step per tile
     ],
 )
 @pytest.mark.parametrize("epilogue", ["plain", "bias_relu", "bias_res_relu"])
@@ -68,6 +72,30 @@ def test_conv2d_nhwc(b, h, w, cin, cout, k, stride, pad, epilogue, device: torch
     got = _conv(xn, conv, act, residual=rn).permute(0, 3, 1, 2).cpu()
     assert got.shape == exp.shape
     assert _rel_err(got, exp) < 1e-5
+
+
+def test_conv1x1_stream_silu_and_residual_after_activation(device: torch.device) -> None:
+    """The streaming 1 x 1 kernel with the EfficientNetV2 epilogues: SiLU, and `act(conv + bias) + residual`."""
+    from imagescry_amd import _lib
+    from imagescry_amd.embedding import _conv
+    from imagescry_amd.resnet50 import FoldedConv
+
+    g = cases.gen(77)
+    b, h, w, cin, cout = 4, 150, 150, 96, 256
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    bias = torch.randn(cout, generator=g)
+    res = torch.randn(b, cout, h, w, generator=g)
+    conv = FoldedConv(wt.permute(0, 2, 3, 1).contiguous().to(device), bias.to(device), 1, 1, 0)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(device)
+    rn = res.permute(0, 2, 3, 1).contiguous().to(device)
+    base = F.conv2d(x, wt, bias)
+    got = _conv(xn, conv, _lib.ISC_ACT_SILU).permute(0, 3, 1, 2).cpu()
+    assert _rel_err(got, F.silu(base)) < 1e-5
+    got = _conv(xn, conv, _lib.ISC_ACT_SILU | _lib.ISC_ACT_RESIDUAL_AFTER, residual=rn).permute(0, 3, 1, 2).cpu()
+    assert _rel_err(got, F.silu(base) + res) < 1e-5
+    got = _conv(xn, conv, _lib.ISC_ACT_NONE, residual=rn).permute(0, 3, 1, 2).cpu()
+    assert _rel_err(got, base + res) < 1e-5
 
 
 @pytest.mark.parametrize("b,h,w,cout,k,stride,pad", [(2, 37, 29, 64, 7, 2, 3), (1, 16, 16, 128, 3, 1, 1), (3, 9, 20, 64, 5, 2, 2)])
