@@ -810,18 +810,26 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     // threads per query.  In the filter levels the survivors come from the lane-private segments written in the hot
     // loop, at level 0 straight from the accumulators.
     {
-        Cand* lists = reinterpret_cast<Cand*>(lds);                      // [64][TAIL_LCAP]
-        int* lcount = reinterpret_cast<int*>(lds + TAIL_COUNT_OFF);     // [64]
+        // level 0 of the 256-query shape with kp = 16 (k <= 10): all 256 queries in ONE pass with 64-entry lists (a
+        // workgroup emits ~1.35 kp = 21 candidates per query there; more than 64 would flag the query for the exact
+        // pass).  Four passes of 64 queries with only two of the eight waves active in each cost 69 of that launch's
+        // 104 us.  Larger kp keep the four passes (256-entry lists).
+        const int PASSES = (SAMPLE && TNQ == 256 && kp <= 16) ? 1 : WN;
+        const int QPP = TNQ / PASSES;             // queries per pass
+        const int LCAP = 64 * TAIL_LCAP / QPP;     // list entries per query: 256 or 64 (128 KiB of lists either way)
+        const int TPQ = NTHREADS / QPP;           // threads per query in the copy-out: 8 or 2
+        Cand* lists = reinterpret_cast<Cand*>(lds);                      // [QPP][LCAP]
+        int* lcount = reinterpret_cast<int*>(lds + TAIL_COUNT_OFF);     // [QPP]
         const int64_t trow0 = r0 + (int64_t)tile_begin * TM + wm * (TM / WM) + fg * 4;  // level 0: the one tile
 #pragma unroll 1
-        for (int pass = 0; pass < WN; ++pass) {
+        for (int pass = 0; pass < PASSES; ++pass) {
             __syncthreads();  // the previous pass has been copied out (first pass: every lane has read its lbound)
-            if (tid < 64) lcount[tid] = 0;
+            if (tid < QPP) lcount[tid] = 0;
             __syncthreads();
-            if (wn == pass) {
+            if (PASSES == 1 || wn == pass) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    const int qc = n * 16 + frow;
+                    const int qc = (PASSES == 1 ? wn * 64 : 0) + n * 16 + frow;
                     if constexpr (SAMPLE) {
 #pragma unroll
                         for (int m = 0; m < MB; ++m)
@@ -830,8 +838,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                                 const float sc = acc[m][n][r];
                                 if (sc > thr[n]) {  // rows past the end are -inf and never pass
                                     const int pos = atomicAdd(&lcount[qc], 1);
-                                    if (pos < TAIL_LCAP)
-                                        lists[qc * TAIL_LCAP + pos] = Cand{sc, (int32_t)(trow0 + m * 16 + r)};
+                                    if (pos < LCAP) lists[qc * LCAP + pos] = Cand{sc, (int32_t)(trow0 + m * 16 + r)};
                                 }
                             }
                     } else {
@@ -849,7 +856,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                             for (int j = 0; j < 4; ++j)
                                 if (i + j < c) {
                                     const int pos = atomicAdd(&lcount[qc], 1);
-                                    if (pos < TAIL_LCAP) lists[qc * TAIL_LCAP + pos] = e[j];
+                                    if (pos < LCAP) lists[qc * LCAP + pos] = e[j];
                                 }
                         }
                     }
@@ -857,20 +864,20 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             }
             __syncthreads();
             {
-                const int qc = tid >> 3, sub = tid & 7;
+                const int qc = tid / TPQ, sub = tid % TPQ;
                 const int q = q0 + pass * 64 + qc;
                 const int c_all = lcount[qc];
-                const int c = min(c_all, TAIL_LCAP);
+                const int c = min(c_all, LCAP);
                 int off = 0;
                 if (sub == 0 && c > 0) off = atomicAdd(&qcount[q], c);
-                off = __shfl(off, lane & ~7, 64);
-                if (sub == 0 && (c_all > TAIL_LCAP || off + c > QCAP)) {
+                off = __shfl(off, lane & ~(TPQ - 1), 64);
+                if (sub == 0 && (c_all > LCAP || off + c > QCAP)) {
                     atomicAdd(&status[0], 1);
                     qflag[q] = 1;
                 }
                 Cand* dst = qlist + (size_t)q * QCAP + off;
-                for (int i = sub; i < c; i += 8)
-                    if (off + i < QCAP) dst[i] = lists[qc * TAIL_LCAP + i];
+                for (int i = sub; i < c; i += TPQ)
+                    if (off + i < QCAP) dst[i] = lists[qc * LCAP + i];
             }
         }
     }
