@@ -103,7 +103,12 @@ __device__ __forceinline__ void gs_mfma_half(const u32x4& a, const u32x4 (&b)[4]
 // DBG (-DISC_ABLATION builds only, ISC_GEMM_DEBUG, wrong results): 1 = no store epilogue, 2 = the token stream re-reads
 // the chunk's first tile (L2 hot), 3 = both, 4 = weights staged once (no re-staging per tile), 5 = fp16 stores to a
 // fully coalesced (wrong) address pattern
-template <int EPI, int DBG>
+// SPLIT: only waves 0 - 3 (wm = 0, one per SIMD) issue the LDS-DMA, twice as many pieces each; waves 4 - 7 never touch the
+// vector-memory counter for the ring.  Their output stores -- half of every tile -- are then bunched right at the end of
+// the tile and nobody ever waits for them; the wm = 0 waves bunch theirs too and leave them in flight with a counted
+// wait.  (scripts/microbench/store_wall.hip: stores bunched behind a tile's MFMAs hide 60 % under the next tile, stores
+// interleaved with MFMAs cost ~150 cycles of matrix issue each, and what really exposes them is a later vmcnt wait.)
+template <int EPI, int DBG, bool SPLIT>
 __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmParams p) {
     constexpr int WN = 4, WM = 2, MB = 8;
     constexpr int LDS_BYTES = (A_ST + B_ST) * TILE_BYTES;
@@ -140,40 +145,66 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
     // chunk.  Token rows are staged in order; weight rows through the permutation described in the header: staging
     // round i covers LDS rows 64 i + t (t = tid >> 3), i.e. wave column wn = i, and LDS row 16 n + r of it takes feature
     // 16 (r >> 2) + 4 n + (r & 3) of the 64 -- a per-lane constant, so the rounds keep their 8 KiB immediates.
-    const int srow = tid >> 3;
+    // SPLIT: the 256 threads of waves 0 - 3 cover 32 rows per round, eight rounds per operand; LDS row 32 i + t of the
+    // weight tile takes feature 64 (i >> 1) + 8 (i & 1) + [16 ((t & 15) >> 2) + 4 (t >> 4) + (t & 3)].
+    const int srow = SPLIT ? (tid & 255) >> 3 : tid >> 3;
     const int spc = tid & 7;
     const int sw16 = (spc ^ ((srow >> 1) & 7)) << 4;
     const int wperm = 16 * ((srow & 15) >> 2) + 4 * (srow >> 4) + (srow & 3);
     const unsigned char* a_stream = p.a + (int64_t)tile_begin * ksteps * TILE_BYTES + srow * 128 + sw16;
     const unsigned char* b_stream = p.w + (int64_t)fb * ksteps * TILE_BYTES + wperm * 128 + sw16;
+    // byte offset of staging round i inside a weight K-step block (SPLIT): rows 64 (i >> 1) + 8 (i & 1)
+    auto wround = [](int i) { return (64 * (i >> 1) + 8 * (i & 1)) * 128; };
 
     unsigned char* const lds_a = lds;
     unsigned char* const lds_b = lds + A_ST * TILE_BYTES;
     const unsigned lds_a_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const unsigned lds_b_addr = lds_a_addr + A_ST * TILE_BYTES;
-    const int wave_dst = wave * 1024;
+    const int wave_dst = (SPLIT ? (wave & 3) : wave) * 1024;
 
     auto issue_a = [&](int step) {
         const unsigned char* src = a_stream + (int64_t)step * TILE_BYTES;
         unsigned char* dst = lds_a + (step % A_ST) * TILE_BYTES + wave_dst;
+        if constexpr (SPLIT) {
+            if (wm == 0) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) gs_dma16(src + 8192 * i, dst + 8192 * i);
+                for (int i = 0; i < 2 * NA; ++i) gs_dma16(src + 4096 * i, dst + 4096 * i);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) gs_dma16(src + 8192 * i, dst + 8192 * i);
+        }
     };
     auto issue_b = [&](int step) {
         const unsigned char* src = b_stream + (int64_t)(step % ksteps) * TILE_BYTES;
         unsigned char* dst = lds_b + (step % B_ST) * TILE_BYTES + wave_dst;
+        if constexpr (SPLIT) {
+            if (wm == 0) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) gs_dma16(src + 8192 * i, dst + 8192 * i);
+                for (int i = 0; i < 2 * NB; ++i) gs_dma16(src + wround(i), dst + 4096 * i);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) gs_dma16(src + 8192 * i, dst + 8192 * i);
+        }
     };
     auto issue_iter = [&](int it) {
         const int sb = it + DB, sa = it + DA;
         if (sb >= 0 && sb < total_steps) issue_b(sb);
         if (sa >= 0 && sa < total_steps) issue_a(sa);
     };
-    // stream order ... B(next) A(next + 1): only A(next + 1) may stay in flight
+    // stream order ... B(next) A(next + 1): only A(next + 1) may stay in flight.  SPLIT: the wm = 1 waves have issued
+    // nothing for the ring and wait for nothing (the barrier after the wm = 0 waves' wait publishes the stage).
     auto retire_for = [&](int next) {
-        if (next + 1 < total_steps) gs_wait_vmcnt<NA>();
-        else gs_wait_vmcnt<0>();
+        if constexpr (SPLIT) {
+            if (wm == 0) {
+                if (next + 1 < total_steps) gs_wait_vmcnt<2 * NA>();
+                else gs_wait_vmcnt<0>();
+            }
+        } else {
+            if (next + 1 < total_steps) gs_wait_vmcnt<NA>();
+            else gs_wait_vmcnt<0>();
+        }
     };
 
     const int fsw = (lane >> 1) & 7;
@@ -199,7 +230,9 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // static priority for the second-dispatched half of the workgroup, as in k_dots_filter
-    if (__builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
+    if constexpr (!SPLIT) {
+        if (__builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
+    }
 
     for (int it = -DA; it < 0; ++it) issue_iter(it);
     retire_for(0);
@@ -260,7 +293,7 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
     // boundary (measured without any epilogue: 0.38 - 0.43 of peak; with all of it at the boundary: 0.17 - 0.34).
     // The float32 + residual epilogue needs loads whose waits would drain the DMA ring eight times per tile; it stays
     // at the boundary (one drain).
-    constexpr bool DEFER = EPI != EPI_F32;
+    constexpr bool DEFER = EPI != EPI_F32 && !SPLIT;
 
     auto main_loop = [&](auto stagger_tag) {
     constexpr bool STAGGER = decltype(stagger_tag)::value;
@@ -294,11 +327,23 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
         GS_DS_READ(ar[1][1], a_addr1, 2048);
 #define GS_EPI(m_) \
     if constexpr (DEFER) { if (pend) epi_block(acc[m_], pend_row0 + (m_) * 16 + frow); }
-#define GS_DMA(j_)                                                        \
-    if ((j_) < 4) {                                                       \
-        if (do_b) gs_dma16(bsrc + 8192 * (j_), bdst + 8192 * (j_));       \
-    } else {                                                              \
-        if (do_a) gs_dma16(asrc + 8192 * ((j_)-4), adst + 8192 * ((j_)-4)); \
+#define GS_DMA(j_)                                                                                  \
+    if constexpr (SPLIT) {                                                                          \
+        if constexpr (!STAGGER) { /* the wm = 0 loop: two pieces per row block */                   \
+            if ((j_) < 4) {                                                                         \
+                if (do_b) {                                                                         \
+                    gs_dma16(bsrc + wround(2 * (j_)), bdst + 4096 * (2 * (j_)));                    \
+                    gs_dma16(bsrc + wround(2 * (j_) + 1), bdst + 4096 * (2 * (j_) + 1));            \
+                }                                                                                   \
+            } else if (do_a) {                                                                      \
+                gs_dma16(asrc + 4096 * (2 * ((j_)-4)), adst + 4096 * (2 * ((j_)-4)));               \
+                gs_dma16(asrc + 4096 * (2 * ((j_)-4) + 1), adst + 4096 * (2 * ((j_)-4) + 1));       \
+            }                                                                                       \
+        }                                                                                           \
+    } else if ((j_) < 4) {                                                                          \
+        if (do_b) gs_dma16(bsrc + 8192 * (j_), bdst + 8192 * (j_));                                 \
+    } else {                                                                                        \
+        if (do_a) gs_dma16(asrc + 8192 * ((j_)-4), adst + 8192 * ((j_)-4));                         \
     }
         if constexpr (STAGGER) {
             // type B: [first half of block m] [reads m + 2, DMA, wait for block m + 1] [second half of block m]
@@ -390,7 +435,15 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
         // retire this wave's DMA for step + 1, then publish.  After a boundary epilogue everything is drained (its loads
         // and stores share the counter).  In a step that carried a deferred epilogue the newest operations are stores
         // and the bank pieces interleaved with them: the counted wait then retires more than it has to, never less.
-        if (drained) {
+        if (drained && SPLIT) {
+            // the tile's stores were issued just now, behind this step's ring pieces.  wm = 1: nothing to wait for.  wm = 0,
+            // packed fp16 output (two unconditional stores per row block): leave the 16 stores and the 8 token pieces
+            // of step + 2 in flight; otherwise (float32 output: residual loads, predicated stores) drain.
+            if (wm == 0) {
+                if (EPI != EPI_F32 && p.out_packed && step + 2 < total_steps) gs_wait_vmcnt<2 * NA + 16>();
+                else gs_wait_vmcnt<0>();
+            }
+        } else if (drained) {
             gs_wait_vmcnt<0>();
         } else if (had_epi && p.out_packed && step + 2 < total_steps) {
             // issue order of this step: [S(0) D0] ... [S(3) D3] [S(4) D4] ... [S(7) D7]  (S = the two stores of a block's
@@ -444,13 +497,23 @@ int isc_gemm_f16_stream_launch(const void* a, long long M, int K, const void* w,
     p.npairs = nchunks * p.ngroups;
     const int slots = ((p.npairs + 7) / 8) * p.group;  // per XCD
     const dim3 grid(8 * slots), block(GTHREADS);
-#define GS_LAUNCH(DBG_)                                                                                          \
-    do {                                                                                                         \
-        if (epi == EPI_F16) hipLaunchKernelGGL((k_gemm_f16_stream<EPI_F16, DBG_>), grid, block, 0, stream, p);   \
-        else if (epi == EPI_F16_GELU)                                                                            \
-            hipLaunchKernelGGL((k_gemm_f16_stream<EPI_F16_GELU, DBG_>), grid, block, 0, stream, p);              \
-        else hipLaunchKernelGGL((k_gemm_f16_stream<EPI_F32, DBG_>), grid, block, 0, stream, p);                  \
+#define GS_LAUNCH_S(DBG_, SPLIT_)                                                                                        \
+    do {                                                                                                                \
+        if (epi == EPI_F16) hipLaunchKernelGGL((k_gemm_f16_stream<EPI_F16, DBG_, SPLIT_>), grid, block, 0, stream, p);  \
+        else if (epi == EPI_F16_GELU)                                                                                   \
+            hipLaunchKernelGGL((k_gemm_f16_stream<EPI_F16_GELU, DBG_, SPLIT_>), grid, block, 0, stream, p);             \
+        else hipLaunchKernelGGL((k_gemm_f16_stream<EPI_F32, DBG_, SPLIT_>), grid, block, 0, stream, p);                 \
     } while (0)
+#ifdef ISC_ABLATION
+    static const bool no_split = getenv("ISC_GEMM_NO_SPLIT") != nullptr;  // A/B aid
+#define GS_LAUNCH(DBG_)                    \
+    do {                                   \
+        if (no_split) GS_LAUNCH_S(DBG_, false); \
+        else GS_LAUNCH_S(DBG_, true);      \
+    } while (0)
+#else
+#define GS_LAUNCH(DBG_) GS_LAUNCH_S(DBG_, true)
+#endif
 #ifdef ISC_ABLATION
     static const int dbg = [] {
         const char* e = getenv("ISC_GEMM_DEBUG");
@@ -465,5 +528,6 @@ int isc_gemm_f16_stream_launch(const void* a, long long M, int K, const void* w,
 #endif
         GS_LAUNCH(0);
 #undef GS_LAUNCH
+#undef GS_LAUNCH_S
     return isc_launch_status();
 }
