@@ -259,6 +259,30 @@ def test_rounding_guard_catches_near_duplicates_of_the_kth_neighbour(dtype: torc
     assert 0.0 < ratio < 0.5, ratio  # observed filter error, in units of the guard's bound
 
 
+def test_every_query_through_the_exact_pass(device: torch.device) -> None:
+    """A bank of 2 000 distinct vectors each stored 100 times: the ten best rows of every query are exact copies of one
+    vector, more copies than the filter carries -- its choice among them cannot be proven, so EVERY query goes through
+    k_exact (64 listed queries = 16 sweeps of 782 tiles in 256 chunks, then the last-workgroup k-way merge).  The answer
+    must be the ten LOWEST original indices of the best vector, exactly as the oracle orders ties."""
+    from oracle import c_oracle
+
+    g = cases.gen(51)
+    base = torch.nn.functional.normalize(torch.randn(2000, 128, generator=g), dim=1)
+    bank = base.repeat(100, 1)[torch.randperm(200_000, generator=g)].half()
+    queries = torch.randn(64, 128, generator=g).half()
+    eb = _bank(bank, device)
+    scores, indices = eb.search(queries.to(device), 10)
+    exp_s, exp_i = c_oracle.cosine_topk(bank.float().numpy(), queries.float().numpy(), 10)
+    _check(scores, indices, exp_s, exp_i)
+    st = eb.last_status.cpu().tolist()
+    assert st[1] == 64, st
+    # the same through the explicit exhaustive entry point, and a second search on the same workspace stays correct
+    es, ei = eb.search_exhaustive(queries.to(device), 10)
+    assert torch.equal(ei, indices) and torch.equal(es, scores)
+    s2, i2 = eb.search(queries[:7].to(device), 10)
+    assert torch.equal(i2, indices[:7]) and torch.equal(s2, scores[:7])
+
+
 def test_guard_bound_holds_for_same_sign_vectors(device: torch.device) -> None:
     """Worst case for the rounding bound: every product q_i * b_i has the same sign, so the running sum is as large as
     sum |q_i b_i| all the way.  status[2] reports max |filter score - exact dot| / bound over the re-scored candidates."""
