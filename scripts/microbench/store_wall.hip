@@ -11,7 +11,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // MODE 0: MFMA only   1: stores only   2: MFMAs then the 16 stores   3: one store after every 48 MFMAs
-//      4: the 16 stores inside the first 64 MFMAs (2 per 8)   5: like 3 but 4-byte stores (scalar-ish traffic)
+//      4: the 16 stores inside the first 96 MFMAs   5: like 3 but 4-byte stores
+//      6: like 3, but only waves 0 - 3 store (two stores after every 48 MFMAs); waves 4 - 7 issue MFMAs only
+//      7: waves 0 - 3 store (two per 48 MFMAs) and issue HALF the MFMAs; waves 4 - 7 issue 1.5 x the MFMAs
 template <int MODE>
 __global__ __launch_bounds__(512) void k(unsigned char* out, int tiles, int n_feat_bytes, float* sink) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -34,14 +36,25 @@ __global__ __launch_bounds__(512) void k(unsigned char* out, int tiles, int n_fe
             for (int s = 0; s < 16; ++s) store(s);
             continue;
         }
+        const bool storer = __builtin_amdgcn_readfirstlane(wave) < 4;
+        if (MODE == 7 && !storer) {  // the partner wave of each SIMD: 1.5 x the matrix work, no memory instructions
 #pragma unroll 1
-        for (int blk = 0; blk < 16; ++blk) {  // 16 blocks of 48 MFMAs = one tile's 768
+            for (int blk = 0; blk < 24; ++blk) {
+#pragma unroll
+                for (int j = 0; j < 48; ++j) acc[j & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[j & 7], 0, 0, 0);
+            }
+            continue;
+        }
+#pragma unroll 1
+        for (int blk = 0; blk < (MODE == 7 ? 8 : 16); ++blk) {  // 16 blocks of 48 MFMAs = one tile's 768
 #pragma unroll
             for (int j = 0; j < 48; ++j) {
                 acc[j & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[j & 7], 0, 0, 0);
                 if (MODE == 4 && blk < 2 && (j % 6) == 5) store(blk * 8 + j / 6);  // 16 stores inside the first 96 MFMAs
             }
             if (MODE == 3 || MODE == 5) store(blk);
+            if (MODE == 6 && storer) { store(blk); store(blk ^ 1); }
+            if (MODE == 7) { store(2 * blk); store(2 * blk + 1); store((2 * blk) ^ 8); store((2 * blk + 1) ^ 8); }
         }
         if (MODE == 2) for (int s = 0; s < 16; ++s) store(s);
     }
@@ -69,10 +82,12 @@ int main() {
     unsigned char* out; float* sink;
     hipMalloc(&out, bytes); hipMalloc(&sink, 4);
     const double mb = bytes / 1e6, flops = 2.0 * 256 * tiles * 8 * 768 * 16 * 16 * 32;
-    const char* names[] = {"MFMA only", "stores only", "MFMAs then 16 stores", "1 store per 48 MFMAs", "16 stores inside the first 96 MFMAs", "1 dword store per 48 MFMAs"};
-    float t[6] = {run<0>(out, tiles, nfb, sink), run<1>(out, tiles, nfb, sink), run<2>(out, tiles, nfb, sink),
-                  run<3>(out, tiles, nfb, sink), run<4>(out, tiles, nfb, sink), run<5>(out, tiles, nfb, sink)};
-    for (int m = 0; m < 6; ++m)
+    const char* names[] = {"MFMA only", "stores only", "MFMAs then 16 stores", "1 store per 48 MFMAs", "16 stores inside the first 96 MFMAs", "1 dword store per 48 MFMAs",
+                           "waves 0-3: 2 stores per 48 MFMAs; 4-7: none", "waves 0-3: stores + 1/2 MFMAs; 4-7: 3/2 MFMAs"};
+    float t[8] = {run<0>(out, tiles, nfb, sink), run<1>(out, tiles, nfb, sink), run<2>(out, tiles, nfb, sink),
+                  run<3>(out, tiles, nfb, sink), run<4>(out, tiles, nfb, sink), run<5>(out, tiles, nfb, sink),
+                  run<6>(out, tiles, nfb, sink), run<7>(out, tiles, nfb, sink)};
+    for (int m = 0; m < 8; ++m)
         printf("%-40s %8.3f ms   %7.1f TFLOP/s   %7.1f GB/s written\n", names[m], t[m], m == 1 ? 0.0 : flops / t[m] / 1e9,
                m == 0 ? 0.0 : (m == 5 ? mb / 4 : mb) / t[m]);
     printf("(%.0f MB of output per launch; MFMA+store perfectly overlapped = max of rows 0 and 1)\n", mb);
