@@ -61,6 +61,7 @@ struct StreamGemmParams {
     long long M;
     int N, ksteps, ntiles, tiles_per_chunk, out_packed;
     int group, ngroups, npairs;  // XCD-aware mapping, see the kernel
+    int seg_off, seg_len;        // this launch covers tiles [seg_off, seg_off + seg_len) of every chunk
 };
 
 #define GS_DS_READ(dst_, addr_, off_) \
@@ -132,8 +133,8 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
     const int fb = (pair % p.ngroups) * p.group + slot % p.group;
     const int ksteps = p.ksteps;
 
-    const int tile_begin = chunk * p.tiles_per_chunk;
-    const int tile_end = min(p.ntiles, tile_begin + p.tiles_per_chunk);
+    const int tile_begin = chunk * p.tiles_per_chunk + p.seg_off;
+    const int tile_end = min(p.ntiles, chunk * p.tiles_per_chunk + min(p.tiles_per_chunk, p.seg_off + p.seg_len));
     const int my_tiles = tile_end - tile_begin;
     if (my_tiles <= 0) return;
     const int total_steps = my_tiles * ksteps;
@@ -469,6 +470,19 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
 
 }  // namespace
 
+// tiles per chunk and launch (0 = whole chunks)
+#ifdef ISC_ABLATION
+static int gemm_seg_tiles() {
+    static const int v = [] {
+        const char* e = getenv("ISC_GEMM_SEG");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+#else
+static constexpr int gemm_seg_tiles() { return 0; }
+#endif
+
 // Called by isc_gemm_f16 for packed operands with N a multiple of 256.  epi: 0 = fp16 out, 1 = fp16 out with GELU,
 // 2 = float32 out (+ optional float32 residual).
 int isc_gemm_f16_stream_launch(const void* a, long long M, int K, const void* w, int N, const float* bias,
@@ -514,19 +528,26 @@ int isc_gemm_f16_stream_launch(const void* a, long long M, int K, const void* w,
 #else
 #define GS_LAUNCH(DBG_) GS_LAUNCH_S(DBG_, true)
 #endif
+    // A long chunk runs as several launches over consecutive tile ranges: the feature-block partners that share a
+    // token chunk through their XCD's L2 drift apart as a launch goes on, and a kernel boundary realigns them.
+    int seg = gemm_seg_tiles();
+    if (seg <= 0 || seg > p.tiles_per_chunk) seg = p.tiles_per_chunk;
+    for (p.seg_off = 0; p.seg_off < p.tiles_per_chunk; p.seg_off += seg) {
+        p.seg_len = seg;
 #ifdef ISC_ABLATION
-    static const int dbg = [] {
-        const char* e = getenv("ISC_GEMM_DEBUG");
-        return e ? atoi(e) : 0;
-    }();
-    if (dbg == 1) GS_LAUNCH(1);
-    else if (dbg == 2) GS_LAUNCH(2);
-    else if (dbg == 3) GS_LAUNCH(3);
-    else if (dbg == 4) GS_LAUNCH(4);
-    else if (dbg == 5) GS_LAUNCH(5);
-    else
+        static const int dbg = [] {
+            const char* e = getenv("ISC_GEMM_DEBUG");
+            return e ? atoi(e) : 0;
+        }();
+        if (dbg == 1) GS_LAUNCH(1);
+        else if (dbg == 2) GS_LAUNCH(2);
+        else if (dbg == 3) GS_LAUNCH(3);
+        else if (dbg == 4) GS_LAUNCH(4);
+        else if (dbg == 5) GS_LAUNCH(5);
+        else
 #endif
-        GS_LAUNCH(0);
+            GS_LAUNCH(0);
+    }
 #undef GS_LAUNCH
 #undef GS_LAUNCH_S
     return isc_launch_status();
