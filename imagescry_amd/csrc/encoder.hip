@@ -48,10 +48,24 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// a 128-byte line of zeros: the LDS-DMA source of filter taps outside the image
+__device__ __attribute__((aligned(128))) const float g_zero_line[32] = {0.f};
+
+__device__ __forceinline__ void conv_dma16(const void* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+#define CONV_DS_READ(dst_, addr_, off_) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_))
+
 // TCO output channels x TPIX pixels per workgroup of 4 waves; every wave owns a 64 x 64 sub-tile.
 // TAP4 = the small-Cin mode of the stem: Cin == 4 (RGB + one zero channel), a K step is 8 filter taps x 4 channels,
 // weights are [Cout][ceil(R*S/8)*8 taps][4] with the padding taps zero.
-template <int TCO, int TPIX, bool TAP4>
+// DMA = stage both operand tiles by LDS-DMA (global_load_lds_dwordx4: the per-lane SOURCE address does the im2col gather,
+// taps that fall outside the image read a page of zeros) instead of global loads into registers + ds_write_b128: no
+// staging registers, no LDS store instructions; the fragment reads then have to be inline asm (a C++ LDS load makes hipcc
+// drain the DMA in flight before it).  Used whenever no per-element transform of x is asked for (`sub`, `scale`).
+template <int TCO, int TPIX, bool TAP4, bool DMA>
 __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
     constexpr int WCO = TCO / 64;          // waves along the output channels
     constexpr int NA = TCO * 8 / 256;      // 16-byte staging slots per thread, weight tile
@@ -185,6 +199,97 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
         for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(b + 4096 * i) = sb[i];
     };
 
+    // LDS-DMA form of load_step + store_step: this thread's slots of K step ks straight into buffer buf.  Wave w's 64
+    // lanes cover rows 8 w .. 8 w + 7 of a staging round (lane-linear 1 KiB), round i is 32 rows (4 KiB) further.
+    auto dma_step = [&](int ks, int buf) {
+        unsigned char* a = lds + buf * BUF_BYTES + (tid >> 6) * 1024;
+        unsigned char* b = a + A_BYTES;
+        if constexpr (TAP4) {
+            const int tap = ks * 8 + lchunk;
+            const int r = tap / p.S;
+            const int s = tap - r * p.S;
+            const bool tap_ok = tap < p.R * p.S;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) conv_dma16(p.w + (size_t)(a_off[i] + ks * 32), a + 4096 * i);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int hi = (b_hw0[i] >> 16) + r;
+                const int wi = (int)(short)(b_hw0[i] & 0xffff) + s;
+                const bool ok = tap_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const float* src = ok ? p.x + (size_t)(b_base[i] + (hi * p.W + wi) * 4) : g_zero_line + lchunk * 4;
+                conv_dma16(src, b + 4096 * i);
+            }
+        } else {
+            const int rs = ks / p.cin_steps;
+            const int c0 = (ks - rs * p.cin_steps) * 32;
+            const int r = rs / p.S;
+            const int s = rs - r * p.S;
+            const int koff = rs * p.Cin + c0;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) conv_dma16(p.w + (size_t)(a_off[i] + koff), a + 4096 * i);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int hi = (b_hw0[i] >> 16) + r;
+                const int wi = (int)(short)(b_hw0[i] & 0xffff) + s;
+                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const float* src = ok ? p.x + (size_t)(b_base[i] + (hi * p.W + wi) * p.Cin + c0) : g_zero_line + lchunk * 4;
+                conv_dma16(src, b + 4096 * i);
+            }
+        }
+    };
+
+    if constexpr (DMA) {
+        dma_step(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // also the bias / residual loads of the accumulators
+        __builtin_amdgcn_s_barrier();
+        const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+        for (int ks = 0; ks < p.ksteps; ++ks) {
+            const int buf = ks & 1;
+            if (ks + 1 < p.ksteps) dma_step(ks + 1, buf ^ 1);
+            const unsigned a_img = lds_addr + buf * BUF_BYTES + wco * 64 * 128;
+            const unsigned b_img = lds_addr + buf * BUF_BYTES + A_BYTES + wpix * 64 * 128;
+            u32x4 a[2][4], b[2][4];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                CONV_DS_READ(a[cc][0], a_img + foff[cc], 0);
+                CONV_DS_READ(a[cc][1], a_img + foff[cc], 2048);
+                CONV_DS_READ(a[cc][2], a_img + foff[cc], 4096);
+                CONV_DS_READ(a[cc][3], a_img + foff[cc], 6144);
+                CONV_DS_READ(b[cc][0], b_img + foff[cc], 0);
+                CONV_DS_READ(b[cc][1], b_img + foff[cc], 2048);
+                CONV_DS_READ(b[cc][2], b_img + foff[cc], 4096);
+                CONV_DS_READ(b[cc][3], b_img + foff[cc], 6144);
+            }
+            asm volatile("s_waitcnt lgkmcnt(8)"
+                         : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]), "+v"(b[0][1]),
+                           "+v"(b[0][2]), "+v"(b[0][3]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[0][mi][j]),
+                                                                           __uint_as_float(b[0][ni][j]), acc[mi][ni], 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[1][0]), "+v"(b[1][1]),
+                           "+v"(b[1][2]), "+v"(b[1][3]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[1][mi][j]),
+                                                                           __uint_as_float(b[1][ni][j]), acc[mi][ni], 0, 0, 0);
+            // the next K step has landed (its DMA flew under this step's 128 MFMAs); everyone is done reading this buffer
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     load_step(0);
     store_step(0);
     __syncthreads();
@@ -215,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
         }
         if (more) store_step(buf ^ 1);
         __syncthreads();
+    }
     }
 
     // ---- epilogue: activation and one 16-byte store per (pixel, four channels)
@@ -354,6 +460,14 @@ int stream_grid(size_t items) {
 int isc_conv1x1_stream_launch(const float* x, long long M, int K, const float* w, int N, const float* bias,
                               const float* residual, int act, int res_after_act, float* out, hipStream_t stream);
 #ifdef ISC_ABLATION
+static bool conv_no_dma() {
+    static const bool v = getenv("ISC_CONV_NO_DMA") != nullptr;  // A/B aid: register-staged operands everywhere
+    return v;
+}
+#else
+static constexpr bool conv_no_dma() { return false; }
+#endif
+#ifdef ISC_ABLATION
 static bool conv_no_stream() {
     static const bool v = getenv("ISC_CONV_NO_STREAM") != nullptr;  // A/B aid
     return v;
@@ -408,10 +522,18 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     if (blocks > 0x7fffffff) return ISC_ERR_UNSUPPORTED;
     isc_timing_begin(ISC_KERNEL_CONV, s);
     const dim3 grid((unsigned)blocks), block(256);
-    if (narrow && tap4) hipLaunchKernelGGL((k_conv_f32<64, 256, true>), grid, block, 0, s, p);
-    else if (narrow) hipLaunchKernelGGL((k_conv_f32<64, 256, false>), grid, block, 0, s, p);
-    else if (tap4) hipLaunchKernelGGL((k_conv_f32<128, 128, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((k_conv_f32<128, 128, false>), grid, block, 0, s, p);
+    const bool dma = !sub && !scale && !conv_no_dma();
+    if (dma) {
+        if (narrow && tap4) hipLaunchKernelGGL((k_conv_f32<64, 256, true, true>), grid, block, 0, s, p);
+        else if (narrow) hipLaunchKernelGGL((k_conv_f32<64, 256, false, true>), grid, block, 0, s, p);
+        else if (tap4) hipLaunchKernelGGL((k_conv_f32<128, 128, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((k_conv_f32<128, 128, false, true>), grid, block, 0, s, p);
+    } else {
+        if (narrow && tap4) hipLaunchKernelGGL((k_conv_f32<64, 256, true, false>), grid, block, 0, s, p);
+        else if (narrow) hipLaunchKernelGGL((k_conv_f32<64, 256, false, false>), grid, block, 0, s, p);
+        else if (tap4) hipLaunchKernelGGL((k_conv_f32<128, 128, true, false>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((k_conv_f32<128, 128, false, false>), grid, block, 0, s, p);
+    }
     isc_timing_end(ISC_KERNEL_CONV, s);
     return isc_launch_status();
 }
