@@ -2,8 +2,10 @@
 # per-layer time / TFLOP/s / GB/s of the ResNet-50 encode step (rocprofv3 kernel trace of scripts/trace_encode.py,
 # k_conv_f32 launches matched in order with the layer table)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+if [ -z "$PARSE_ONLY" ]; then
 rm -rf gpurun_out/prof_enc
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_enc -- python3 scripts/trace_encode.py > gpurun_out/prof_enc.log 2>&1
+fi
 python3 - <<'PY'
 import csv, glob
 B = 512
@@ -26,7 +28,8 @@ for li, (planes, nb, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2),
         inpl = planes * 4
         h = h2
 layers.append(("fc 2048->768", B, 2048, 768, B * 2048 * 4, B * 768 * 4, 0))
-f = glob.glob("gpurun_out/prof_enc/*/*kernel_trace.csv")[0]
+import os
+f = max(glob.glob("gpurun_out/prof_enc/*/*kernel_trace.csv"), key=os.path.getmtime)
 rows = [r for r in csv.DictReader(open(f)) if "k_conv_f32" in r["Kernel_Name"] or "k_conv1x1_f32_stream" in r["Kernel_Name"]]
 n = len(layers)
 last = rows[-n:]
@@ -37,7 +40,8 @@ for (name, m, k, nn, ib, ob, rb), r in zip(layers, last):
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     fl = 2.0 * m * k * nn
     tot_t += us; tot_f += fl
-    tile = ("stream " if "stream" in r["Kernel_Name"] else "") + r["Kernel_Name"].split("<")[1].split(">")[0]
+    kn = r["Kernel_Name"]
+    tile = "ring 128, 256" if "ring" in kn else ("stream " if "stream" in kn else "") + kn.split("<")[1].split(">")[0]
     print(f"{name:22s} {m:9d} {k:5d} {nn:5d} {us:8.1f} {fl/us/1e6:8.1f} {fl/us/1e6/157.3:7.2f} {(ib+ob+rb)/us/1e3:7.0f}  {tile}")
     kind = name.split(".")[-1].split(" ")[0] if name.startswith("l") else name.split(" ")[0]
     a = agg.setdefault(name[:2] + " " + kind, [0, 0]); a[0] += us; a[1] += fl
