@@ -525,8 +525,8 @@ def bench_encode_efficientnet(args: argparse.Namespace, device: torch.device, st
             "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
             "kernel_ms_per_step": round(kernel_ms / steps, 3),
             "algorithmic_flops_per_step": flops,
-            "note": "algorithmic FLOPs use the true channel counts; the kernel pads channel counts to multiples of 32 "
-                    "(24 -> 32, 48 -> 64 in the first stages) and so executes more; depthwise convolutions and the "
+            "note": "algorithmic FLOPs use the true channel counts, which is also what the kernel runs (24- and "
+                    "48-channel stages in its packed-K mode, no padding to 32); depthwise convolutions and the "
                     "squeeze-excitation pooling (not matrix-core work) take the rest of the step",
         },
     }

@@ -35,6 +35,7 @@ struct ConvParams {
     int M;          // B * Ho * Wo output pixels
     int K;          // R * S * Cin
     int cin_steps;  // Cin / 32
+    int cin4;       // packed-K mode: 16-byte chunks per filter tap (Cin / 4)
     int ksteps;     // R * S * cin_steps
     int act;
     int res_after_act;  // out = act(conv + bias) + residual instead of act(conv + bias + residual)
@@ -59,8 +60,10 @@ __device__ __forceinline__ void conv_dma16(const void* gsrc, unsigned char* lds_
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_))
 
 // TCO output channels x TPIX pixels per workgroup of 4 waves; every wave owns a 64 x 64 sub-tile.
-// TAP4 = the small-Cin mode of the stem: Cin == 4 (RGB + one zero channel), a K step is 8 filter taps x 4 channels,
-// weights are [Cout][ceil(R*S/8)*8 taps][4] with the padding taps zero.
+// TAP4 = packed-K mode, for Cin % 32 != 0 (Cin % 4 == 0): the reduction axis k = (r * S + s) * Cin + c is cut into
+// 128-byte K steps regardless of tap boundaries -- every lane's 16-byte chunk (4 channels) finds its own filter tap --
+// and weights are [Cout][ceil(R*S*Cin / 32) * 32] with the tail zero.  Cin == 4 (the stem: RGB + one zero channel) is
+// the case "8 taps per K step"; 24- and 48-channel stages of EfficientNetV2 run unpadded this way.
 // DMA = stage both operand tiles by LDS-DMA (global_load_lds_dwordx4: the per-lane SOURCE address does the im2col gather,
 // taps that fall outside the image read a page of zeros) instead of global loads into registers + ds_write_b128: no
 // staging registers, no LDS store instructions; the fragment reads then have to be inline asm (a C++ LDS load makes hipcc
@@ -145,8 +148,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
 
     auto load_step = [&](int ks) {
         if constexpr (TAP4) {
-            // this thread's 16-byte chunk is one filter tap (4 channels): tap = 8 * ks + logical chunk
-            const int tap = ks * 8 + lchunk;
+            // this thread's 16-byte chunk: chunk kc of the flattened (tap, channel / 4) axis
+            const int kc = ks * 8 + lchunk;
+            const int tap = kc / p.cin4;
+            const int c4 = kc - tap * p.cin4;
             const int r = tap / p.S;
             const int s = tap - r * p.S;
             const bool tap_ok = tap < p.R * p.S;
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
                 const int wi = (int)(short)(b_hw0[i] & 0xffff) + s;
                 const bool ok = tap_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 u32x4 v = u32x4{0u, 0u, 0u, 0u};
-                if (ok) v = *reinterpret_cast<const u32x4*>(p.x + (size_t)(b_base[i] + (hi * p.W + wi) * 4));
+                if (ok) v = *reinterpret_cast<const u32x4*>(p.x + (size_t)(b_base[i] + (hi * p.W + wi) * p.Cin + c4 * 4));
                 sb[i] = v;
             }
         } else {
@@ -205,7 +210,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
         unsigned char* a = lds + buf * BUF_BYTES + (tid >> 6) * 1024;
         unsigned char* b = a + A_BYTES;
         if constexpr (TAP4) {
-            const int tap = ks * 8 + lchunk;
+            const int kc = ks * 8 + lchunk;
+            const int tap = kc / p.cin4;
+            const int c4 = kc - tap * p.cin4;
             const int r = tap / p.S;
             const int s = tap - r * p.S;
             const bool tap_ok = tap < p.R * p.S;
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
                 const int hi = (b_hw0[i] >> 16) + r;
                 const int wi = (int)(short)(b_hw0[i] & 0xffff) + s;
                 const bool ok = tap_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                const float* src = ok ? p.x + (size_t)(b_base[i] + (hi * p.W + wi) * 4) : g_zero_line + lchunk * 4;
+                const float* src = ok ? p.x + (size_t)(b_base[i] + (hi * p.W + wi) * p.Cin + c4 * 4) : g_zero_line + lchunk * 4;
                 conv_dma16(src, b + 4096 * i);
             }
         } else {
@@ -484,15 +491,15 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     const int res_after_act = (act & ISC_ACT_RESIDUAL_AFTER) ? 1 : 0;
     act &= ~ISC_ACT_RESIDUAL_AFTER;
     ISC_REQUIRE(act >= ISC_ACT_NONE && act <= ISC_ACT_SIGMOID);
-    if (scale && (Cin == 4 || !isc_aligned(scale, 16))) return ISC_ERR_UNSUPPORTED;
-    const bool tap4 = Cin == 4;  // stem mode: w is [Cout][ceil(R*S/8)*8][4]
-    if ((!tap4 && Cin % 32 != 0) || Cout % 4 != 0) return ISC_ERR_UNSUPPORTED;  // pad channels with zeros
+    if (Cin % 4 != 0 || Cout % 4 != 0) return ISC_ERR_UNSUPPORTED;  // pad channels with zeros
+    const bool tap4 = Cin % 32 != 0;  // packed-K mode: w is [Cout][ceil(R*S*Cin/32)*32]
+    if ((scale || sub) && (tap4 || (scale && !isc_aligned(scale, 16)))) return ISC_ERR_UNSUPPORTED;
     if (H > 16384 || W > 16384 || pad > 8192) return ISC_ERR_UNSUPPORTED;
     const int Ho = (H + 2 * pad - R) / stride + 1;
     const int Wo = (W + 2 * pad - S) / stride + 1;
     ISC_REQUIRE(Ho > 0 && Wo > 0);
     const int64_t M = (int64_t)B * Ho * Wo;
-    const int ksteps = tap4 ? isc_ceil_div(R * S, 8) : R * S * (Cin / 32);
+    const int ksteps = tap4 ? isc_ceil_div(R * S * Cin, 32) : R * S * (Cin / 32);
     const int64_t K = (int64_t)ksteps * 32;
     if ((int64_t)B * H * W * Cin >= (1ll << 31) || M * Cout >= (1ll << 31) || (int64_t)Cout * K >= (1ll << 31))
         return ISC_ERR_UNSUPPORTED;  // 32-bit element offsets inside the kernel
@@ -502,7 +509,7 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.res = residual; p.sub = sub; p.scale = scale; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
-    p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = tap4 ? 1 : Cin / 32; p.ksteps = ksteps; p.act = act; p.res_after_act = res_after_act;
+    p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = tap4 ? 1 : Cin / 32; p.cin4 = Cin / 4; p.ksteps = ksteps; p.act = act; p.res_after_act = res_after_act;
     hipStream_t s = isc_stream(stream);
     // 1 x 1, stride 1, whole 256-channel output blocks, a residual, at most four K steps, enough pixel tiles to fill the
     // chip (ResNet-50 layer1 / layer2 expand convolutions): the streaming kernel of conv1x1_stream.hip, +6 % there.

@@ -11,9 +11,10 @@ connections where stride is 1 and the channel count is unchanged; overall stride
 Values of this encoder are *parity unpinned* by the reference (its only test is the output shape,
 tests/test_models/test_embedding.py:97-106); they are held to `oracle/efficientnet_oracle.py`.
 
-Execution: NHWC float32 activations with every channel count padded to a multiple of 32 (zero weights / biases in
-the padding, which SiLU keeps at zero), BatchNorm folded into the convolutions; kernels: `isc_conv2d_nhwc`
-(stem in "stem mode", 3x3 and 1x1 convolutions, squeeze-excitation linears), `isc_dwconv2d_nhwc`,
+Execution: NHWC float32 activations at their TRUE channel counts (all multiples of 4; a count that is not would be
+zero-padded to the next one), BatchNorm folded into the convolutions; kernels: `isc_conv2d_nhwc` (3x3 and 1x1
+convolutions, squeeze-excitation linears; inputs whose channel count is not a multiple of 32 -- the RGB stem, the 24-
+and 48-channel stages -- run in its packed-K mode instead of being padded to 32), `isc_dwconv2d_nhwc`,
 `isc_global_avgpool_nhwc`, `isc_conv2d_nhwc_gated` (projection with the SE gate fused in).
 """
 
@@ -186,20 +187,33 @@ def make_state_dict(size: str = "s", *, seed: int = 0, randomize_bn: bool = Fals
     return sd
 
 
-def pad32(c: int) -> int:
-    return (c + 31) // 32 * 32
+def pad4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+def _krsc(w: Tensor, cout_pad: int, cin_pad: int) -> Tensor:
+    """[Cout, Cin, k, k] -> the kernel's [Cout, K] rows, K = k * k * Cin rounded up to whole 32-float K steps (a no-op
+    when Cin % 32 == 0; otherwise the packed-K layout of include/imagescry_hip.h)."""
+    cout, cin, k, _ = w.shape
+    wk = torch.zeros((cout_pad, k, k, cin_pad), dtype=torch.float32)
+    wk[:cout, :, :, :cin] = w.permute(0, 2, 3, 1).float()
+    flat = wk.reshape(cout_pad, k * k * cin_pad)
+    kpad = (flat.shape[1] + 31) // 32 * 32
+    if kpad != flat.shape[1]:
+        flat = torch.cat([flat, torch.zeros((cout_pad, kpad - flat.shape[1]), dtype=torch.float32)], dim=1)
+    return flat.contiguous()
 
 
 @dataclass
 class Conv:
-    """A convolution with BatchNorm folded in, KRSC weights zero-padded to the kernels' channel multiples."""
+    """A convolution with BatchNorm folded in, weights as the kernel's [Cout, K] rows (`_krsc`)."""
 
     weight: Tensor
     bias: Tensor
     kernel: int
     stride: int
     pad: int
-    cout: int  # padded output channels
+    cout: int  # output channels (a multiple of 4)
 
     def to(self, device: torch.device | str) -> "Conv":
         return Conv(self.weight.to(device), self.bias.to(device), self.kernel, self.stride, self.pad, self.cout)
@@ -238,12 +252,10 @@ def _fold(sd: dict[str, Tensor], conv: str, bn: str | None, stride: int) -> Conv
         w = w * scale[:, None, None, None]
     else:
         shift = sd[f"{conv}.bias"].double()
-    cop, cip = pad32(cout), pad32(cin)
-    wk = torch.zeros((cop, k, k, cip), dtype=torch.float32)
-    wk[:cout, :, :, :cin] = w.permute(0, 2, 3, 1).float()
+    cop = pad4(cout)
     bias = torch.zeros(cop, dtype=torch.float32)
     bias[:cout] = shift.float()
-    return Conv(wk.contiguous(), bias, k, stride, k // 2, cop)
+    return Conv(_krsc(w, cop, pad4(cin)), bias, k, stride, k // 2, cop)
 
 
 def _fold_depthwise(sd: dict[str, Tensor], conv: str, bn: str, stride: int) -> Conv:
@@ -251,7 +263,7 @@ def _fold_depthwise(sd: dict[str, Tensor], conv: str, bn: str, stride: int) -> C
     c, _, k, _ = w.shape
     scale, shift = _bn_scale_shift(sd, bn)
     w = w[:, 0] * scale[:, None, None]
-    cp = pad32(c)
+    cp = pad4(c)
     wk = torch.zeros((k, k, cp), dtype=torch.float32)
     wk[:, :, :c] = w.permute(1, 2, 0).float()
     bias = torch.zeros(cp, dtype=torch.float32)
@@ -264,12 +276,10 @@ def _fold_stem(sd: dict[str, Tensor]) -> Conv:
     scale, shift = _bn_scale_shift(sd, "features.0.1")
     w = w * scale[:, None, None, None]
     cout = w.shape[0]
-    cop = pad32(cout)
-    wk = torch.zeros((cop, 16, 4), dtype=torch.float32)  # 9 taps padded to 16, RGB + zero channel ("stem mode")
-    wk[:cout, :9, :3] = w.permute(0, 2, 3, 1).reshape(cout, 9, 3).float()
+    cop = pad4(cout)
     bias = torch.zeros(cop, dtype=torch.float32)
     bias[:cout] = shift.float()
-    return Conv(wk.contiguous(), bias, 3, 2, 1, cop)
+    return Conv(_krsc(w, cop, 4), bias, 3, 2, 1, cop)  # RGB + one zero channel, 9 taps -> two K steps
 
 
 def fold_state_dict(sd: dict[str, Tensor], size: str = "s") -> FoldedEfficientNet:

@@ -217,7 +217,7 @@ class ResNet50Embedder(EmbeddingModule):
         net = self._net
         b, c, h, w = x.shape
         ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
-        # stem: NCHW -> NHWC with a zero fourth channel, then the 7x7 / 2 convolution in the kernel's "stem mode"
+        # stem: NCHW -> NHWC with a zero fourth channel, then the 7x7 / 2 convolution in the kernel's packed-K mode
         x4 = torch.empty((b, h, w, 4), dtype=torch.float32, device=x.device)
         _lib.check(lib.isc_nchw_to_nhwc(x.data_ptr(), b, c, h, w, 4, x4.data_ptr(), stream), "isc_nchw_to_nhwc")
         y = torch.empty((b, ho, wo, 64), dtype=torch.float32, device=x.device)

@@ -140,8 +140,11 @@ int isc_nchw_to_nhwc(const float* x, int B, int C, int H, int W, int Cpad, float
 /* out = act(conv2d(x, w) + bias [+ residual]) as an implicit GEMM on the f32 matrix cores.
  * The build's stand-in for the torchvision backbone the reference calls at
  * src/imagescry/models/embedding.py:167-177 (BatchNorm folded into w / bias by the host).
- *   x        float [B,H,W,Cin]         NHWC, Cin % 32 == 0 -- or Cin == 4 ("stem mode", RGB + one zero channel)
- *   w        float [Cout,R,S,Cin]      KRSC; in stem mode [Cout, ceil(R*S/8)*8, 4] with the padding taps zero
+ *   x        float [B,H,W,Cin]         NHWC, Cin % 4 == 0.  Cin % 32 != 0 selects "packed-K mode" (the RGB stem as
+ *                                      RGB + one zero channel, 24- / 48-channel stages): no residual restriction, but
+ *                                      no `gate` (isc_conv2d_nhwc_gated) and no centring (isc_linear_centered)
+ *   w        float [Cout,R,S,Cin]      KRSC; in packed-K mode every row [R*S*Cin] is zero-padded to a multiple of 32
+ *                                      floats, i.e. [Cout, ceil(R*S*Cin/32)*32]
  *   bias     float [Cout] or NULL
  *   residual float [B,Ho,Wo,Cout] or NULL (added before the activation)
  *   out      float [B,Ho,Wo,Cout],  Ho = (H + 2*pad - R)/stride + 1 (same for Wo)

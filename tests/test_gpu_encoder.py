@@ -100,7 +100,7 @@ def test_conv1x1_stream_silu_and_residual_after_activation(device: torch.device)
 
 @pytest.mark.parametrize("b,h,w,cout,k,stride,pad", [(2, 37, 29, 64, 7, 2, 3), (1, 16, 16, 128, 3, 1, 1), (3, 9, 20, 64, 5, 2, 2)])
 def test_conv2d_stem_mode(b, h, w, cout, k, stride, pad, device: torch.device) -> None:
-    """Cin == 4 (RGB + zero channel): a K step is eight filter taps; weights [Cout, ceil(k*k/8)*8, 4]."""
+    """Cin == 4 (RGB + zero channel), the packed-K mode with eight filter taps per K step; weights [Cout, ceil(k*k/8)*8, 4]."""
     from imagescry_amd import _lib
 
     g = cases.gen(b + h + cout)
@@ -123,6 +123,62 @@ def test_conv2d_stem_mode(b, h, w, cout, k, stride, pad, device: torch.device) -
                              _lib.ISC_ACT_RELU, out.data_ptr(), stream)
     _lib.check(st, "isc_conv2d_nhwc")
     assert _rel_err(out.permute(0, 3, 1, 2).cpu(), exp) < 1e-5
+
+
+@pytest.mark.parametrize(
+    "b,h,w,cin,cout,k,stride,pad",
+    [
+        (2, 31, 29, 24, 24, 3, 1, 1),  # EfficientNetV2-S stage 1 (6 chunks per tap: K steps straddle taps)
+        (2, 30, 30, 24, 96, 3, 2, 1),  # stage 2 expand
+        (2, 17, 19, 48, 192, 3, 1, 1),  # 48 channels: 12 chunks per tap
+        (3, 20, 20, 96, 48, 1, 1, 0),  # Cin % 32 == 0 but Cout = 48: the plain mode, unpadded output
+        (3, 20, 20, 48, 64, 1, 1, 0),  # 1 x 1 packed-K: 1.5 K steps, tail zero-padded
+        (2, 9, 9, 80, 160, 1, 1, 0),  # EfficientNetV2-M: 80 = 2.5 K steps
+        (2, 9, 9, 8, 132, 5, 2, 2),  # 2 chunks per tap, Cout over one 128 tile
+        (4, 1, 1, 40, 960, 1, 1, 0),  # squeeze-excitation fc2 from an unpadded squeeze width
+    ],
+)
+@pytest.mark.parametrize("epilogue", ["bias_silu", "bias_silu_then_res"])
+def test_conv2d_packed_k_mode(b, h, w, cin, cout, k, stride, pad, epilogue, device: torch.device) -> None:
+    """Cin % 32 != 0: weights [Cout, ceil(k*k*Cin/32)*32], every 16-byte chunk of a K step finds its own filter tap."""
+    from imagescry_amd import _lib
+
+    g = cases.gen(b * 100 + cin + cout + k)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    exp = F.silu(F.conv2d(x, wt, bias, stride=stride, padding=pad))
+    res = torch.randn(exp.shape, generator=g) if epilogue == "bias_silu_then_res" else None
+    if res is not None:
+        exp = exp + res
+    kk = k * k * cin
+    wk = torch.zeros(cout, (kk + 31) // 32 * 32)
+    wk[:, :kk] = wt.permute(0, 2, 3, 1).reshape(cout, kk)
+    lib = _lib.load()
+    stream = _lib.stream_handle(device)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(device)
+    rn = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(device)
+    ho, wo = exp.shape[-2:]
+    out = torch.empty((b, ho, wo, cout), device=device)
+    wd, bd = wk.to(device), bias.to(device)
+    act = _lib.ISC_ACT_SILU | (_lib.ISC_ACT_RESIDUAL_AFTER if res is not None else 0)
+    st = lib.isc_conv2d_nhwc(xn.data_ptr(), b, h, w, cin, wd.data_ptr(), cout, k, k, stride, pad, bd.data_ptr(),
+                             _lib.ptr(rn), act, out.data_ptr(), stream)
+    _lib.check(st, "isc_conv2d_nhwc")
+    assert _rel_err(out.permute(0, 3, 1, 2).cpu(), exp) < 1e-5
+
+
+def test_conv2d_packed_k_mode_refuses_gate(device: torch.device) -> None:
+    from imagescry_amd import _lib
+
+    lib = _lib.load()
+    x = torch.zeros((1, 4, 4, 24), device=device)
+    w = torch.zeros((32, 32), device=device)
+    gate = torch.ones((1, 24), device=device)
+    out = torch.empty((1, 4, 4, 32), device=device)
+    st = lib.isc_conv2d_nhwc_gated(x.data_ptr(), 1, 4, 4, 24, gate.data_ptr(), w.data_ptr(), 32, 1, 1, 1, 0, None, None,
+                                   _lib.ISC_ACT_NONE, out.data_ptr(), _lib.stream_handle(device))
+    assert st == _lib.ISC_ERR_UNSUPPORTED
 
 
 def test_im2col_maxpool_avgpool(device: torch.device) -> None:
