@@ -84,6 +84,11 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
         c_int,
         [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
     ),
+    "isc_dwconv2d_nhwc_pool": (
+        c_int,
+        [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+         c_void_p],
+    ),
     "isc_linear_centered": (
         c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
     ),

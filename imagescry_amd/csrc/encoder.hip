@@ -445,6 +445,100 @@ __global__ __launch_bounds__(256) void k_dwconv_nhwc(const float* __restrict__ x
     }
 }
 
+// Depthwise 3 x 3, stride 1, pad 1 -- the MBConv case -- as a row sweep: one thread = four channels of a strip of TW
+// output columns, walking down the image with the three input rows of the window in registers, so every input element
+// is loaded once per strip ((TW + 2) / TW loads per output instead of nine; the nine-fold re-read of k_dwconv_nhwc goes
+// through the L2 and is what bounds it).  Lanes = consecutive channel vectors of one pixel: each load / store
+// instruction of a wave is one contiguous 1 KiB.  POOL: also the mean over the image of the activated output (the
+// squeeze-excitation pooling), written directly (one strip) or with one atomicAdd per strip into a zeroed [B, C]
+// (two strips: a + b in either order is the same float).
+template <int TW, bool POOL>
+__global__ __launch_bounds__(256) void k_dwconv3x3_rows(const float* __restrict__ x, int H, int W, int C,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        int act, int strips, size_t total, float* __restrict__ y,
+                                                        float* __restrict__ pooled, float inv_hw) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cvec = C / 4;
+    const int cv = (int)(i % cvec);
+    const size_t t = i / cvec;
+    const int strip = (int)(t % strips);
+    const size_t b = t / strips;
+    const int w0 = strip * TW;
+
+    f32x4 k[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) k[j] = *reinterpret_cast<const f32x4*>(w + (size_t)j * C + cv * 4);
+    const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + cv * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xb = x + b * H * W * C + cv * 4;
+    float* yb = y + b * H * W * C + cv * 4;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load_row = [&](int hi, f32x4 (&dst)[TW + 2]) {
+        const bool row_ok = hi < H;  // hi >= 0 always here
+#pragma unroll
+        for (int j = 0; j < TW + 2; ++j) {
+            const int wi = w0 - 1 + j;
+            dst[j] = (row_ok && (unsigned)wi < (unsigned)W)
+                         ? *reinterpret_cast<const f32x4*>(xb + ((size_t)hi * W + wi) * C) : zero;
+        }
+    };
+    f32x4 sum = zero;
+    // rows a, b2 hold input rows ho - 1 and ho; c receives row ho + 1; then output row ho
+    auto step = [&](f32x4 (&a)[TW + 2], f32x4 (&b2)[TW + 2], f32x4 (&c)[TW + 2], int ho) {
+        load_row(ho + 1, c);
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            if (w0 + j >= W) break;
+            f32x4 acc = bv;
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[e] = fmaf(a[j + s2][e], k[s2][e], acc[e]);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[e] = fmaf(b2[j + s2][e], k[3 + s2][e], acc[e]);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[e] = fmaf(c[j + s2][e], k[6 + s2][e], acc[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = apply_act(acc[e], act);
+            if (POOL) sum += acc;
+            *reinterpret_cast<f32x4*>(yb + ((size_t)ho * W + w0 + j) * C) = acc;
+        }
+    };
+
+    f32x4 r0[TW + 2], r1[TW + 2], r2[TW + 2];
+#pragma unroll
+    for (int j = 0; j < TW + 2; ++j) r0[j] = zero;  // row -1
+    load_row(0, r1);
+    for (int ho = 0; ho < H; ho += 3) {
+        step(r0, r1, r2, ho);
+        if (ho + 1 < H) step(r1, r2, r0, ho + 1);
+        if (ho + 2 < H) step(r2, r0, r1, ho + 2);
+    }
+    if (POOL) {
+        float* pp = pooled + b * C + cv * 4;
+        if (strips == 1) {
+            *reinterpret_cast<f32x4*>(pp) = sum * inv_hw;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(pp + e, sum[e] * inv_hw);
+        }
+    }
+}
+
 // grid (ceil(C / 256), B): thread = one channel, loop over the HW positions (coalesced across channels)
 __global__ __launch_bounds__(256) void k_global_avgpool_nhwc(const float* __restrict__ x, int HW, int C,
                                                              float* __restrict__ y) {
@@ -601,6 +695,15 @@ extern "C" int isc_maxpool_nhwc(const float* x, int B, int H, int W, int C, int 
     return isc_launch_status();
 }
 
+#ifdef ISC_ABLATION
+static bool dwconv_no_rows() {
+    static const bool v = getenv("ISC_DWCONV_NO_ROWS") != nullptr;  // A/B aid: the one-pixel-per-thread kernel everywhere
+    return v;
+}
+#else
+static constexpr bool dwconv_no_rows() { return false; }
+#endif
+
 extern "C" int isc_dwconv2d_nhwc(const float* x, int B, int H, int W, int C, const float* w, int R, int stride, int pad,
                                  const float* bias, int act, float* y, void* stream) {
     ISC_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && R > 0 && stride > 0 && pad >= 0);
@@ -608,6 +711,8 @@ extern "C" int isc_dwconv2d_nhwc(const float* x, int B, int H, int W, int C, con
     if (C % 4 != 0) return ISC_ERR_UNSUPPORTED;
     if (!isc_aligned(x, 16) || !isc_aligned(w, 16) || !isc_aligned(y, 16) || (bias && !isc_aligned(bias, 16)))
         return ISC_ERR_ALIGNMENT;
+    if (R == 3 && stride == 1 && pad == 1 && !dwconv_no_rows())  // the row-sweep kernel
+        return isc_dwconv2d_nhwc_pool(x, B, H, W, C, w, R, stride, pad, bias, act, y, nullptr, stream);
     const int Ho = (H + 2 * pad - R) / stride + 1;
     const int Wo = (W + 2 * pad - R) / stride + 1;
     ISC_REQUIRE(Ho > 0 && Wo > 0);
@@ -615,6 +720,39 @@ extern "C" int isc_dwconv2d_nhwc(const float* x, int B, int H, int W, int C, con
     hipLaunchKernelGGL(k_dwconv_nhwc, dim3(stream_grid(total4)), dim3(256), 0, isc_stream(stream), x, H, W, C, R, stride,
                        pad, Ho, Wo, w, bias, act, total4, y);
     return isc_launch_status();
+}
+
+extern "C" int isc_dwconv2d_nhwc_pool(const float* x, int B, int H, int W, int C, const float* w, int R, int stride,
+                                      int pad, const float* bias, int act, float* y, float* pooled, void* stream) {
+    ISC_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && R > 0 && stride > 0 && pad >= 0);
+    ISC_REQUIRE(act >= ISC_ACT_NONE && act <= ISC_ACT_SIGMOID);
+    if (C % 4 != 0) return ISC_ERR_UNSUPPORTED;
+    if (!isc_aligned(x, 16) || !isc_aligned(w, 16) || !isc_aligned(y, 16) || (bias && !isc_aligned(bias, 16)) ||
+        (pooled && !isc_aligned(pooled, 16)))
+        return ISC_ERR_ALIGNMENT;
+    hipStream_t s = isc_stream(stream);
+    constexpr int TW = 7;
+    const int strips = isc_ceil_div(W, TW);
+    const bool rows = R == 3 && stride == 1 && pad == 1 && !dwconv_no_rows();
+    if (rows && (!pooled || strips <= 2)) {
+        const size_t total = (size_t)B * strips * (C / 4);
+        const size_t blocks = isc_ceil_div(total, (size_t)256);
+        if (blocks > 0x7fffffff) return ISC_ERR_UNSUPPORTED;
+        if (pooled) {
+            if (strips > 1 && hipMemsetAsync(pooled, 0, (size_t)B * C * sizeof(float), s) != hipSuccess) return ISC_ERR_LAUNCH;
+            hipLaunchKernelGGL((k_dwconv3x3_rows<TW, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, H, W, C, w, bias,
+                               act, strips, total, y, pooled, 1.f / (float)(H * W));
+        } else {
+            hipLaunchKernelGGL((k_dwconv3x3_rows<TW, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, H, W, C, w, bias,
+                               act, strips, total, y, nullptr, 0.f);
+        }
+        return isc_launch_status();
+    }
+    const int st = isc_dwconv2d_nhwc(x, B, H, W, C, w, R, stride, pad, bias, act, y, stream);
+    if (st != ISC_OK || !pooled) return st;
+    const int Ho = (H + 2 * pad - R) / stride + 1;
+    const int Wo = (W + 2 * pad - R) / stride + 1;
+    return isc_global_avgpool_nhwc(y, B, Ho, Wo, C, pooled, stream);
 }
 
 extern "C" int isc_global_avgpool_nhwc(const float* x, int B, int H, int W, int C, float* y, void* stream) {

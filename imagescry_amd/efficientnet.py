@@ -14,8 +14,8 @@ tests/test_models/test_embedding.py:97-106); they are held to `oracle/efficientn
 Execution: NHWC float32 activations at their TRUE channel counts (all multiples of 4; a count that is not would be
 zero-padded to the next one), BatchNorm folded into the convolutions; kernels: `isc_conv2d_nhwc` (3x3 and 1x1
 convolutions, squeeze-excitation linears; inputs whose channel count is not a multiple of 32 -- the RGB stem, the 24-
-and 48-channel stages -- run in its packed-K mode instead of being padded to 32), `isc_dwconv2d_nhwc`,
-`isc_global_avgpool_nhwc`, `isc_conv2d_nhwc_gated` (projection with the SE gate fused in).
+and 48-channel stages -- run in its packed-K mode instead of being padded to 32),
+`isc_dwconv2d_nhwc_pool` (depthwise + the SE mean), `isc_conv2d_nhwc_gated` (projection with the SE gate fused in).
 """
 
 from __future__ import annotations
@@ -323,25 +323,20 @@ def _conv(x: Tensor, c: Conv, act: int, *, residual: Tensor | None = None, gate:
     return out
 
 
-def _depthwise(x: Tensor, c: Conv, act: int) -> Tensor:
+def _depthwise(x: Tensor, c: Conv, act: int) -> tuple[Tensor, Tensor]:
+    """Depthwise convolution + activation, and the squeeze-excitation mean of its output `[B, 1, 1, C]` (from the same
+    kernel where the shape allows, include/imagescry_hip.h: isc_dwconv2d_nhwc_pool)."""
     b, h, w, ch = x.shape
     ho = (h + 2 * c.pad - c.kernel) // c.stride + 1
     wo = (w + 2 * c.pad - c.kernel) // c.stride + 1
     out = torch.empty((b, ho, wo, ch), dtype=torch.float32, device=x.device)
+    pooled = torch.empty((b, 1, 1, ch), dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    st = lib.isc_dwconv2d_nhwc(x.data_ptr(), b, h, w, ch, c.weight.data_ptr(), c.kernel, c.stride, c.pad,
-                               c.bias.data_ptr(), act, out.data_ptr(), _lib.stream_handle(x.device))
-    _lib.check(st, "isc_dwconv2d_nhwc")
-    return out
-
-
-def _avgpool(x: Tensor) -> Tensor:
-    b, h, w, ch = x.shape
-    out = torch.empty((b, 1, 1, ch), dtype=torch.float32, device=x.device)
-    lib = _lib.load()
-    _lib.check(lib.isc_global_avgpool_nhwc(x.data_ptr(), b, h, w, ch, out.data_ptr(), _lib.stream_handle(x.device)),
-               "isc_global_avgpool_nhwc")
-    return out
+    st = lib.isc_dwconv2d_nhwc_pool(x.data_ptr(), b, h, w, ch, c.weight.data_ptr(), c.kernel, c.stride, c.pad,
+                                    c.bias.data_ptr(), act, out.data_ptr(), pooled.data_ptr(),
+                                    _lib.stream_handle(x.device))
+    _lib.check(st, "isc_dwconv2d_nhwc_pool")
+    return out, pooled
 
 
 def forward_features(net: FoldedEfficientNet, x: Tensor) -> Tensor:
@@ -366,8 +361,8 @@ def forward_features(net: FoldedEfficientNet, x: Tensor) -> Tensor:
                 y = _conv(t, blk.convs["project"], none, residual=skip)
         else:
             t = _conv(y, blk.convs["expand"], silu)
-            t = _depthwise(t, blk.convs["depthwise"], silu)
-            g = _conv(_avgpool(t), blk.convs["fc1"], silu)
+            t, pooled = _depthwise(t, blk.convs["depthwise"], silu)
+            g = _conv(pooled, blk.convs["fc1"], silu)
             g = _conv(g, blk.convs["fc2"], sigmoid)
             y = _conv(t, blk.convs["project"], none, residual=skip, gate=g.reshape(b, -1))
     return _conv(y, net.head, silu)

@@ -164,6 +164,13 @@ int isc_conv2d_nhwc_gated(const float* x, int B, int H, int W, int Cin, const fl
 int isc_dwconv2d_nhwc(const float* x, int B, int H, int W, int C, const float* w, int R, int stride, int pad,
                       const float* bias, int act, float* y, void* stream);
 
+/* isc_dwconv2d_nhwc plus, when `pooled` is not NULL, pooled[B, C] = mean over (Ho, Wo) of y: the squeeze-excitation
+ * average pool of the same MBConv block (torchvision `SqueezeExcitation.avgpool`, reached through
+ * src/imagescry/models/embedding.py:133-147), produced by the depthwise kernel itself for 3 x 3 / stride 1 / pad 1 and
+ * W <= 14 instead of by a second pass over y (isc_global_avgpool_nhwc, which other shapes fall back to). */
+int isc_dwconv2d_nhwc_pool(const float* x, int B, int H, int W, int C, const float* w, int R, int stride, int pad,
+                           const float* bias, int act, float* y, float* pooled, void* stream);
+
 /* out[n, K] = (x[n, F] - mean[F]) . w[K, F]^T + bias[K]   (mean and bias may be NULL; F % 32 == 0, K % 4 == 0).
  * The centring happens before the product, as in `torch.matmul(x - feature_means, component_vectors)` of
  * reference src/imagescry/models/decomposition.py:91 (`PCA.forward`); w is `component_vectors` transposed. */

@@ -68,6 +68,54 @@ def test_depthwise_and_gated_conv_kernels(device: torch.device) -> None:
     np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize(
+    "b,h,w,c,k,stride",
+    [
+        (3, 14, 14, 64, 3, 1),  # row-sweep kernel, two strips: pooled by one atomicAdd per strip
+        (5, 7, 7, 96, 3, 1),  # one strip: pooled written directly
+        (2, 9, 10, 40, 3, 1),  # ragged second strip (3 of 7 columns), H not a multiple of 3
+        (2, 1, 1, 32, 3, 1),  # a single pixel
+        (2, 5, 30, 32, 3, 1),  # five strips: sweep kernel, pooled by the separate pass
+        (2, 15, 15, 64, 3, 2),  # stride 2: the one-pixel-per-thread kernel + separate pooling
+        (2, 12, 12, 32, 5, 1),  # 5 x 5: same
+    ],
+)
+def test_depthwise_with_pooled_mean(b, h, w, c, k, stride, device: torch.device) -> None:
+    """isc_dwconv2d_nhwc_pool against torch: y = SiLU(dwconv + bias), pooled = mean of y over the image; and
+    isc_dwconv2d_nhwc returns the same y."""
+    from imagescry_amd import _lib
+
+    lib = _lib.load()
+    stream = _lib.stream_handle(device)
+    g = cases.gen(b + h * 31 + w + c)
+    x = torch.randn(b, c, h, w, generator=g)
+    wt = torch.randn(c, 1, k, k, generator=g) * 0.3
+    bias = torch.randn(c, generator=g)
+    exp = F.silu(F.conv2d(x, wt, bias, stride=stride, padding=k // 2, groups=c))
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device)
+    wd = wt[:, 0].permute(1, 2, 0).contiguous().to(device)
+    bd = bias.to(device)
+    ho, wo = exp.shape[2], exp.shape[3]
+    out = torch.empty((b, ho, wo, c), device=device)
+    pooled = torch.full((b, c), float("nan"), device=device)
+    st = lib.isc_dwconv2d_nhwc_pool(xd.data_ptr(), b, h, w, c, wd.data_ptr(), k, stride, k // 2, bd.data_ptr(),
+                                    _lib.ISC_ACT_SILU, out.data_ptr(), pooled.data_ptr(), stream)
+    _lib.check(st, "isc_dwconv2d_nhwc_pool")
+    np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pooled.cpu().numpy(), exp.mean(dim=(2, 3)).numpy(), rtol=1e-5, atol=1e-6)
+    out2 = torch.empty_like(out)
+    st = lib.isc_dwconv2d_nhwc(xd.data_ptr(), b, h, w, c, wd.data_ptr(), k, stride, k // 2, bd.data_ptr(),
+                               _lib.ISC_ACT_SILU, out2.data_ptr(), stream)
+    _lib.check(st, "isc_dwconv2d_nhwc")
+    assert torch.equal(out, out2)
+    # pooled == NULL is the plain depthwise convolution
+    out3 = torch.empty_like(out)
+    st = lib.isc_dwconv2d_nhwc_pool(xd.data_ptr(), b, h, w, c, wd.data_ptr(), k, stride, k // 2, bd.data_ptr(),
+                                    _lib.ISC_ACT_SILU, out3.data_ptr(), None, stream)
+    _lib.check(st, "isc_dwconv2d_nhwc_pool")
+    assert torch.equal(out, out3)
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 3, 35, 42)])
 def test_efficientnet_s_forward_matches_oracle(shape: tuple[int, ...], device: torch.device) -> None:
     from imagescry_amd import EfficientNetEmbedder, efficientnet
