@@ -617,7 +617,9 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
         isc_timing_end(ISC_KERNEL_CONV, s);
         return st;
     }
-    const bool narrow = Cout <= 64;
+    // 64-channel tiles wherever they pad Cout less than 128-channel ones do (Cout <= 64, but also 160 -> 192 instead of
+    // 256, 192 -> 192 instead of 256): the wasted quarter of the matrix work is worth more than the extra tile reloads
+    const bool narrow = isc_ceil_div(Cout, 64) * 64 < isc_ceil_div(Cout, 128) * 128;
     const int64_t blocks = narrow ? isc_ceil_div(Cout, 64) * isc_ceil_div<int64_t>(M, 256)
                                   : isc_ceil_div(Cout, 128) * isc_ceil_div<int64_t>(M, 128);
     if (blocks > 0x7fffffff) return ISC_ERR_UNSUPPORTED;
