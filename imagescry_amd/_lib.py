@@ -89,6 +89,10 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
         [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
          c_void_p],
     ),
+    "isc_se_gate": (
+        c_int,
+        [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    ),
     "isc_linear_centered": (
         c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
     ),

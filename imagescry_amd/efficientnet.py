@@ -15,7 +15,7 @@ Execution: NHWC float32 activations at their TRUE channel counts (all multiples 
 zero-padded to the next one), BatchNorm folded into the convolutions; kernels: `isc_conv2d_nhwc` (3x3 and 1x1
 convolutions, squeeze-excitation linears; inputs whose channel count is not a multiple of 32 -- the RGB stem, the 24-
 and 48-channel stages -- run in its packed-K mode instead of being padded to 32),
-`isc_dwconv2d_nhwc_pool` (depthwise + the SE mean), `isc_conv2d_nhwc_gated` (projection with the SE gate fused in).
+`isc_dwconv2d_nhwc_pool` (depthwise + the SE mean), `isc_se_gate` (both SE linears), `isc_conv2d_nhwc_gated` (projection with the SE gate fused in).
 """
 
 from __future__ import annotations
@@ -105,8 +105,9 @@ def block_specs(size: str) -> list[list[BlockSpec]]:
 
 def conv_flops(size: str, batch: int, height: int, width: int) -> int:
     """Multiply-add FLOPs (2 per MAC) of the DENSE convolutions of one forward pass (stem, expand / fused / project /
-    squeeze-excitation / head convolutions -- the launches of `k_conv_f32`), from the stage table with the true channel
-    counts (no padding); depthwise convolutions are not matrix-core work and are left out.  For the MFMA roofline."""
+    head convolutions -- the launches of `k_conv_f32`), from the stage table with the true channel counts (no
+    padding); depthwise convolutions and the squeeze-excitation linears (`k_se_gate`) are not matrix-core work and are
+    left out.  For the MFMA roofline."""
     def down(n: int, s: int) -> int:
         return (n + s - 1) // s
 
@@ -124,7 +125,6 @@ def conv_flops(size: str, batch: int, height: int, width: int) -> int:
                     total += 2 * batch * h2 * w2 * b.expanded * b.cin * k2 + 2 * batch * h2 * w2 * b.cout * b.expanded
             else:
                 total += 2 * batch * h * w * b.expanded * b.cin  # expand 1x1 (input resolution)
-                total += 2 * 2 * batch * b.expanded * b.squeeze  # squeeze-excitation fc1 + fc2
                 total += 2 * batch * h2 * w2 * b.cout * b.expanded  # project
             h, w, last = h2, w2, b.cout
     total += 2 * batch * h * w * LAST_CHANNELS * last  # head 1x1
@@ -339,9 +339,21 @@ def _depthwise(x: Tensor, c: Conv, act: int) -> tuple[Tensor, Tensor]:
     return out, pooled
 
 
+def _se_gate(pooled: Tensor, fc1: Conv, fc2: Conv) -> Tensor:
+    """`sigmoid(fc2(silu(fc1(pooled))))` as one launch (include/imagescry_hip.h: isc_se_gate): `[B, 1, 1, C]` -> `[B, C]`."""
+    b, ch = pooled.shape[0], pooled.shape[-1]
+    gate = torch.empty((b, ch), dtype=torch.float32, device=pooled.device)
+    lib = _lib.load()
+    st = lib.isc_se_gate(pooled.data_ptr(), b, ch, fc1.weight.data_ptr(), fc1.weight.shape[1], fc1.bias.data_ptr(),
+                         fc1.cout, fc2.weight.data_ptr(), fc2.weight.shape[1], fc2.bias.data_ptr(), gate.data_ptr(),
+                         _lib.stream_handle(pooled.device))
+    _lib.check(st, "isc_se_gate")
+    return gate
+
+
 def forward_features(net: FoldedEfficientNet, x: Tensor) -> Tensor:
     """float32 NCHW `[B, 3, H, W]` -> float32 NHWC `[B, ceil(H/32), ceil(W/32), 1280]`."""
-    silu, none, sigmoid = _lib.ISC_ACT_SILU, _lib.ISC_ACT_NONE, _lib.ISC_ACT_SIGMOID
+    silu, none = _lib.ISC_ACT_SILU, _lib.ISC_ACT_NONE
     lib = _lib.load()
     b, c, h, w = x.shape
     x4 = torch.empty((b, h, w, 4), dtype=torch.float32, device=x.device)
@@ -362,7 +374,6 @@ def forward_features(net: FoldedEfficientNet, x: Tensor) -> Tensor:
         else:
             t = _conv(y, blk.convs["expand"], silu)
             t, pooled = _depthwise(t, blk.convs["depthwise"], silu)
-            g = _conv(pooled, blk.convs["fc1"], silu)
-            g = _conv(g, blk.convs["fc2"], sigmoid)
-            y = _conv(t, blk.convs["project"], none, residual=skip, gate=g.reshape(b, -1))
+            g = _se_gate(pooled, blk.convs["fc1"], blk.convs["fc2"])
+            y = _conv(t, blk.convs["project"], none, residual=skip, gate=g)
     return _conv(y, net.head, silu)

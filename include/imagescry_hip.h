@@ -171,6 +171,14 @@ int isc_dwconv2d_nhwc(const float* x, int B, int H, int W, int C, const float* w
 int isc_dwconv2d_nhwc_pool(const float* x, int B, int H, int W, int C, const float* w, int R, int stride, int pad,
                            const float* bias, int act, float* y, float* pooled, void* stream);
 
+/* Squeeze-excitation gate: gate[B, C] = sigmoid(w2 . silu(w1 . pooled + b1) + b2) -- torchvision's
+ * `SqueezeExcitation` (fc1, SiLU, fc2, Sigmoid on the pooled map) inside the MBConv blocks the reference runs through
+ * src/imagescry/models/embedding.py:133-147.  pooled float [B, C]; w1 float [S, ld1] (row stride ld1 >= C floats),
+ * b1 float [S] or NULL; w2 float [C, ld2] (ld2 >= S), b2 float [C] or NULL; C, S, ld1, ld2 multiples of 4,
+ * C + S <= 8192. */
+int isc_se_gate(const float* pooled, int B, int C, const float* w1, int ld1, const float* b1, int S, const float* w2,
+                int ld2, const float* b2, float* gate, void* stream);
+
 /* out[n, K] = (x[n, F] - mean[F]) . w[K, F]^T + bias[K]   (mean and bias may be NULL; F % 32 == 0, K % 4 == 0).
  * The centring happens before the product, as in `torch.matmul(x - feature_means, component_vectors)` of
  * reference src/imagescry/models/decomposition.py:91 (`PCA.forward`); w is `component_vectors` transposed. */

@@ -116,6 +116,31 @@ def test_depthwise_with_pooled_mean(b, h, w, c, k, stride, device: torch.device)
     assert torch.equal(out, out3)
 
 
+@pytest.mark.parametrize("b,c,s,ld1,ld2", [(5, 1536, 64, 1536, 64), (3, 256, 16, 256, 32), (1, 40, 12, 64, 32), (2, 3840, 160, 3840, 160)])
+def test_se_gate(b, c, s, ld1, ld2, device: torch.device) -> None:
+    """isc_se_gate against torch: sigmoid(fc2(silu(fc1(pooled)))), weight rows with a stride wider than the row."""
+    from imagescry_amd import _lib
+
+    lib = _lib.load()
+    g = cases.gen(b + c + s)
+    pooled = torch.randn(b, c, generator=g)
+    w1 = torch.randn(s, c, generator=g) / c ** 0.5
+    b1 = torch.randn(s, generator=g)
+    w2 = torch.randn(c, s, generator=g) / s ** 0.5
+    b2 = torch.randn(c, generator=g)
+    exp = torch.sigmoid(F.silu(pooled.double() @ w1.double().T + b1.double()) @ w2.double().T + b2.double()).float()
+    w1p = torch.zeros(s, ld1)
+    w1p[:, :c] = w1
+    w2p = torch.zeros(c, ld2)
+    w2p[:, :s] = w2
+    pd, w1d, b1d, w2d, b2d = (t.to(device) for t in (pooled, w1p, b1, w2p, b2))
+    gate = torch.empty((b, c), device=device)
+    st = lib.isc_se_gate(pd.data_ptr(), b, c, w1d.data_ptr(), ld1, b1d.data_ptr(), s, w2d.data_ptr(), ld2, b2d.data_ptr(),
+                         gate.data_ptr(), _lib.stream_handle(device))
+    _lib.check(st, "isc_se_gate")
+    np.testing.assert_allclose(gate.cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 3, 35, 42)])
 def test_efficientnet_s_forward_matches_oracle(shape: tuple[int, ...], device: torch.device) -> None:
     from imagescry_amd import EfficientNetEmbedder, efficientnet
