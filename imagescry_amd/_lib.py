@@ -87,7 +87,7 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "isc_dwconv2d_nhwc_pool": (
         c_int,
         [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
-         c_void_p],
+         c_void_p, c_void_p],
     ),
     "isc_se_gate": (
         c_int,

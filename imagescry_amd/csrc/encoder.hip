@@ -452,11 +452,15 @@ __global__ __launch_bounds__(256) void k_dwconv_nhwc(const float* __restrict__ x
 // instruction of a wave is one contiguous 1 KiB.  POOL: also the mean over the image of the activated output (the
 // squeeze-excitation pooling), written directly (one strip) or with one atomicAdd per strip into a zeroed [B, C]
 // (two strips: a + b in either order is the same float).
-template <int TW, bool POOL>
+// WRITE = false is the pooling alone (no y), GATE multiplies the activated output by gate[b, c] before the store: an
+// MBConv block runs the kernel twice -- pooled mean, k_se_gate, then y = act(dw) * gate -- so that its 1 x 1 projection is
+// a plain convolution (the gate applied while staging the projection's input doubled that convolution's time; the
+// second read of x here costs a quarter of that).
+template <int TW, bool WRITE, bool POOL, bool GATE>
 __global__ __launch_bounds__(256) void k_dwconv3x3_rows(const float* __restrict__ x, int H, int W, int C,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
-                                                        int act, int strips, size_t total, float* __restrict__ y,
-                                                        float* __restrict__ pooled, float inv_hw) {
+                                                        int act, int strips, size_t total, const float* __restrict__ gate,
+                                                        float* __restrict__ y, float* __restrict__ pooled, float inv_hw) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int cvec = C / 4;
@@ -473,6 +477,8 @@ __global__ __launch_bounds__(256) void k_dwconv3x3_rows(const float* __restrict_
     const float* xb = x + b * H * W * C + cv * 4;
     float* yb = y + b * H * W * C + cv * 4;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 gv = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (GATE) gv = *reinterpret_cast<const f32x4*>(gate + b * C + cv * 4);
 
     auto load_row = [&](int hi, f32x4 (&dst)[TW + 2]) {
         const bool row_ok = hi < H;  // hi >= 0 always here
@@ -515,7 +521,8 @@ __global__ __launch_bounds__(256) void k_dwconv3x3_rows(const float* __restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = apply_act(acc[e], act);
             if (POOL) sum += acc;
-            *reinterpret_cast<f32x4*>(yb + ((size_t)ho * W + w0 + j) * C) = acc;
+            if (GATE) acc *= gv;
+            if (WRITE) *reinterpret_cast<f32x4*>(yb + ((size_t)ho * W + w0 + j) * C) = acc;
         }
     };
 
@@ -787,7 +794,7 @@ extern "C" int isc_dwconv2d_nhwc(const float* x, int B, int H, int W, int C, con
     if (!isc_aligned(x, 16) || !isc_aligned(w, 16) || !isc_aligned(y, 16) || (bias && !isc_aligned(bias, 16)))
         return ISC_ERR_ALIGNMENT;
     if (R == 3 && stride == 1 && pad == 1 && !dwconv_no_rows())  // the row-sweep kernel
-        return isc_dwconv2d_nhwc_pool(x, B, H, W, C, w, R, stride, pad, bias, act, y, nullptr, stream);
+        return isc_dwconv2d_nhwc_pool(x, B, H, W, C, w, R, stride, pad, bias, act, nullptr, y, nullptr, stream);
     const int Ho = (H + 2 * pad - R) / stride + 1;
     const int Wo = (W + 2 * pad - R) / stride + 1;
     ISC_REQUIRE(Ho > 0 && Wo > 0);
@@ -798,12 +805,14 @@ extern "C" int isc_dwconv2d_nhwc(const float* x, int B, int H, int W, int C, con
 }
 
 extern "C" int isc_dwconv2d_nhwc_pool(const float* x, int B, int H, int W, int C, const float* w, int R, int stride,
-                                      int pad, const float* bias, int act, float* y, float* pooled, void* stream) {
-    ISC_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && R > 0 && stride > 0 && pad >= 0);
+                                      int pad, const float* bias, int act, const float* gate, float* y, float* pooled,
+                                      void* stream) {
+    ISC_REQUIRE(x && w && (y || pooled) && B > 0 && H > 0 && W > 0 && C > 0 && R > 0 && stride > 0 && pad >= 0);
     ISC_REQUIRE(act >= ISC_ACT_NONE && act <= ISC_ACT_SIGMOID);
+    ISC_REQUIRE(!gate || y);
     if (C % 4 != 0) return ISC_ERR_UNSUPPORTED;
-    if (!isc_aligned(x, 16) || !isc_aligned(w, 16) || !isc_aligned(y, 16) || (bias && !isc_aligned(bias, 16)) ||
-        (pooled && !isc_aligned(pooled, 16)))
+    if (!isc_aligned(x, 16) || !isc_aligned(w, 16) || (y && !isc_aligned(y, 16)) || (bias && !isc_aligned(bias, 16)) ||
+        (pooled && !isc_aligned(pooled, 16)) || (gate && !isc_aligned(gate, 16)))
         return ISC_ERR_ALIGNMENT;
     hipStream_t s = isc_stream(stream);
     constexpr int TW = 7;
@@ -813,16 +822,22 @@ extern "C" int isc_dwconv2d_nhwc_pool(const float* x, int B, int H, int W, int C
         const size_t total = (size_t)B * strips * (C / 4);
         const size_t blocks = isc_ceil_div(total, (size_t)256);
         if (blocks > 0x7fffffff) return ISC_ERR_UNSUPPORTED;
-        if (pooled) {
-            if (strips > 1 && hipMemsetAsync(pooled, 0, (size_t)B * C * sizeof(float), s) != hipSuccess) return ISC_ERR_LAUNCH;
-            hipLaunchKernelGGL((k_dwconv3x3_rows<TW, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, H, W, C, w, bias,
-                               act, strips, total, y, pooled, 1.f / (float)(H * W));
-        } else {
-            hipLaunchKernelGGL((k_dwconv3x3_rows<TW, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, H, W, C, w, bias,
-                               act, strips, total, y, nullptr, 0.f);
-        }
+        if (pooled && strips > 1 && hipMemsetAsync(pooled, 0, (size_t)B * C * sizeof(float), s) != hipSuccess)
+            return ISC_ERR_LAUNCH;
+        const dim3 grid((unsigned)blocks), block(256);
+        const float inv_hw = 1.f / (float)(H * W);
+#define ISC_DW_ROWS(WRITE_, POOL_, GATE_)                                                                               \
+    hipLaunchKernelGGL((k_dwconv3x3_rows<TW, WRITE_, POOL_, GATE_>), grid, block, 0, s, x, H, W, C, w, bias, act, strips, \
+                       total, gate, y, pooled, inv_hw)
+        if (!y) ISC_DW_ROWS(false, true, false);
+        else if (pooled && gate) ISC_DW_ROWS(true, true, true);
+        else if (pooled) ISC_DW_ROWS(true, true, false);
+        else if (gate) ISC_DW_ROWS(true, false, true);
+        else ISC_DW_ROWS(true, false, false);
+#undef ISC_DW_ROWS
         return isc_launch_status();
     }
+    if (!y || gate) return ISC_ERR_UNSUPPORTED;  // the pooling alone and the gated output exist in the row-sweep kernel only
     const int st = isc_dwconv2d_nhwc(x, B, H, W, C, w, R, stride, pad, bias, act, y, stream);
     if (st != ISC_OK || !pooled) return st;
     const int Ho = (H + 2 * pad - R) / stride + 1;

@@ -323,20 +323,26 @@ def _conv(x: Tensor, c: Conv, act: int, *, residual: Tensor | None = None, gate:
     return out
 
 
-def _depthwise(x: Tensor, c: Conv, act: int) -> tuple[Tensor, Tensor]:
-    """Depthwise convolution + activation, and the squeeze-excitation mean of its output `[B, 1, 1, C]` (from the same
-    kernel where the shape allows, include/imagescry_hip.h: isc_dwconv2d_nhwc_pool)."""
+def _depthwise(x: Tensor, c: Conv, act: int, *, gate: Tensor | None = None, want_y: bool = True,
+               want_pooled: bool = False) -> tuple[Tensor | None, Tensor | None]:
+    """`y = act(dwconv(x) + bias) [* gate]` and / or the squeeze-excitation mean `[B, 1, 1, C]` of the un-gated output
+    (include/imagescry_hip.h: isc_dwconv2d_nhwc_pool)."""
     b, h, w, ch = x.shape
     ho = (h + 2 * c.pad - c.kernel) // c.stride + 1
     wo = (w + 2 * c.pad - c.kernel) // c.stride + 1
-    out = torch.empty((b, ho, wo, ch), dtype=torch.float32, device=x.device)
-    pooled = torch.empty((b, 1, 1, ch), dtype=torch.float32, device=x.device)
+    out = torch.empty((b, ho, wo, ch), dtype=torch.float32, device=x.device) if want_y else None
+    pooled = torch.empty((b, 1, 1, ch), dtype=torch.float32, device=x.device) if want_pooled else None
     lib = _lib.load()
     st = lib.isc_dwconv2d_nhwc_pool(x.data_ptr(), b, h, w, ch, c.weight.data_ptr(), c.kernel, c.stride, c.pad,
-                                    c.bias.data_ptr(), act, out.data_ptr(), pooled.data_ptr(),
+                                    c.bias.data_ptr(), act, _lib.ptr(gate), _lib.ptr(out), _lib.ptr(pooled),
                                     _lib.stream_handle(x.device))
     _lib.check(st, "isc_dwconv2d_nhwc_pool")
     return out, pooled
+
+
+def _sweep_shape(c: Conv, w: int) -> bool:
+    """The shapes for which the depthwise kernel can pool without writing and can gate its output."""
+    return c.kernel == 3 and c.stride == 1 and c.pad == 1 and w <= 14
 
 
 def _se_gate(pooled: Tensor, fc1: Conv, fc2: Conv) -> Tensor:
@@ -373,7 +379,15 @@ def forward_features(net: FoldedEfficientNet, x: Tensor) -> Tensor:
                 y = _conv(t, blk.convs["project"], none, residual=skip)
         else:
             t = _conv(y, blk.convs["expand"], silu)
-            t, pooled = _depthwise(t, blk.convs["depthwise"], silu)
-            g = _se_gate(pooled, blk.convs["fc1"], blk.convs["fc2"])
-            y = _conv(t, blk.convs["project"], none, residual=skip, gate=g)
+            dw = blk.convs["depthwise"]
+            if _sweep_shape(dw, t.shape[2]):
+                # two sweeps of the depthwise kernel (mean first, then the gated output): the projection stays plain
+                _, pooled = _depthwise(t, dw, silu, want_y=False, want_pooled=True)
+                g = _se_gate(pooled, blk.convs["fc1"], blk.convs["fc2"])
+                t, _ = _depthwise(t, dw, silu, gate=g)
+                y = _conv(t, blk.convs["project"], none, residual=skip)
+            else:
+                t, pooled = _depthwise(t, dw, silu, want_pooled=True)
+                g = _se_gate(pooled, blk.convs["fc1"], blk.convs["fc2"])
+                y = _conv(t, blk.convs["project"], none, residual=skip, gate=g)
     return _conv(y, net.head, silu)

@@ -164,12 +164,16 @@ int isc_conv2d_nhwc_gated(const float* x, int B, int H, int W, int Cin, const fl
 int isc_dwconv2d_nhwc(const float* x, int B, int H, int W, int C, const float* w, int R, int stride, int pad,
                       const float* bias, int act, float* y, void* stream);
 
-/* isc_dwconv2d_nhwc plus, when `pooled` is not NULL, pooled[B, C] = mean over (Ho, Wo) of y: the squeeze-excitation
- * average pool of the same MBConv block (torchvision `SqueezeExcitation.avgpool`, reached through
- * src/imagescry/models/embedding.py:133-147), produced by the depthwise kernel itself for 3 x 3 / stride 1 / pad 1 and
- * W <= 14 instead of by a second pass over y (isc_global_avgpool_nhwc, which other shapes fall back to). */
+/* The depthwise stage of an MBConv block with its squeeze-excitation neighbours folded in (torchvision `MBConv`:
+ * depthwise conv, `SqueezeExcitation.avgpool`, scale; reached through src/imagescry/models/embedding.py:133-147):
+ *   pooled[B, C] = mean over (Ho, Wo) of act(dwconv(x, w) + bias)             when `pooled` is not NULL
+ *   y            = act(dwconv(x, w) + bias) [* gate[b, c] when `gate` != NULL] when `y` is not NULL
+ * For 3 x 3 / stride 1 / pad 1 the depthwise kernel produces both itself (`pooled` needs W <= 14, else a second pass over
+ * y by isc_global_avgpool_nhwc); y == NULL (the pooling alone) and `gate` exist for that shape only, other shapes
+ * return ISC_ERR_UNSUPPORTED for them.  A block runs it twice -- pooled, isc_se_gate, then the gated y -- which makes the
+ * block's projection a plain isc_conv2d_nhwc; isc_conv2d_nhwc_gated is the route for the other shapes. */
 int isc_dwconv2d_nhwc_pool(const float* x, int B, int H, int W, int C, const float* w, int R, int stride, int pad,
-                           const float* bias, int act, float* y, float* pooled, void* stream);
+                           const float* bias, int act, const float* gate, float* y, float* pooled, void* stream);
 
 /* Squeeze-excitation gate: gate[B, C] = sigmoid(w2 . silu(w1 . pooled + b1) + b2) -- torchvision's
  * `SqueezeExcitation` (fc1, SiLU, fc2, Sigmoid on the pooled map) inside the MBConv blocks the reference runs through

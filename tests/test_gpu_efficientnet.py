@@ -81,8 +81,8 @@ def test_depthwise_and_gated_conv_kernels(device: torch.device) -> None:
     ],
 )
 def test_depthwise_with_pooled_mean(b, h, w, c, k, stride, device: torch.device) -> None:
-    """isc_dwconv2d_nhwc_pool against torch: y = SiLU(dwconv + bias), pooled = mean of y over the image; and
-    isc_dwconv2d_nhwc returns the same y."""
+    """isc_dwconv2d_nhwc_pool against torch: y = SiLU(dwconv + bias) [* gate], pooled = mean of the un-gated y over the
+    image; the pooling alone and the gated output in the shapes that have them; isc_dwconv2d_nhwc returns the same y."""
     from imagescry_amd import _lib
 
     lib = _lib.load()
@@ -91,16 +91,22 @@ def test_depthwise_with_pooled_mean(b, h, w, c, k, stride, device: torch.device)
     x = torch.randn(b, c, h, w, generator=g)
     wt = torch.randn(c, 1, k, k, generator=g) * 0.3
     bias = torch.randn(c, generator=g)
+    gate = torch.rand(b, c, generator=g)
     exp = F.silu(F.conv2d(x, wt, bias, stride=stride, padding=k // 2, groups=c))
     xd = x.permute(0, 2, 3, 1).contiguous().to(device)
     wd = wt[:, 0].permute(1, 2, 0).contiguous().to(device)
-    bd = bias.to(device)
+    bd, gd = bias.to(device), gate.to(device)
     ho, wo = exp.shape[2], exp.shape[3]
-    out = torch.empty((b, ho, wo, c), device=device)
-    pooled = torch.full((b, c), float("nan"), device=device)
-    st = lib.isc_dwconv2d_nhwc_pool(xd.data_ptr(), b, h, w, c, wd.data_ptr(), k, stride, k // 2, bd.data_ptr(),
-                                    _lib.ISC_ACT_SILU, out.data_ptr(), pooled.data_ptr(), stream)
-    _lib.check(st, "isc_dwconv2d_nhwc_pool")
+
+    def run(gate_t, want_y, want_pooled):
+        out = torch.full((b, ho, wo, c), float("nan"), device=device) if want_y else None
+        pooled = torch.full((b, c), float("nan"), device=device) if want_pooled else None
+        st = lib.isc_dwconv2d_nhwc_pool(xd.data_ptr(), b, h, w, c, wd.data_ptr(), k, stride, k // 2, bd.data_ptr(),
+                                        _lib.ISC_ACT_SILU, _lib.ptr(gate_t), _lib.ptr(out), _lib.ptr(pooled), stream)
+        return st, out, pooled
+
+    st, out, pooled = run(None, True, True)
+    assert st == 0
     np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(pooled.cpu().numpy(), exp.mean(dim=(2, 3)).numpy(), rtol=1e-5, atol=1e-6)
     out2 = torch.empty_like(out)
@@ -108,12 +114,23 @@ def test_depthwise_with_pooled_mean(b, h, w, c, k, stride, device: torch.device)
                                _lib.ISC_ACT_SILU, out2.data_ptr(), stream)
     _lib.check(st, "isc_dwconv2d_nhwc")
     assert torch.equal(out, out2)
-    # pooled == NULL is the plain depthwise convolution
-    out3 = torch.empty_like(out)
-    st = lib.isc_dwconv2d_nhwc_pool(xd.data_ptr(), b, h, w, c, wd.data_ptr(), k, stride, k // 2, bd.data_ptr(),
-                                    _lib.ISC_ACT_SILU, out3.data_ptr(), None, stream)
-    _lib.check(st, "isc_dwconv2d_nhwc_pool")
-    assert torch.equal(out, out3)
+    st, out3, _ = run(None, True, False)  # pooled == NULL is the plain depthwise convolution
+    assert st == 0 and torch.equal(out, out3)
+
+    sweep = k == 3 and stride == 1
+    st, _, pooled_only = run(None, False, True)
+    st_g, out_g, pooled_g = run(gd, True, True)
+    if sweep and w <= 14:
+        assert st == 0 and torch.equal(pooled_only, pooled)  # same sums in the same order
+        assert st_g == 0 and torch.equal(pooled_g, pooled)  # the mean is of the un-gated output
+        # y * gate is one float32 multiply of the un-gated y
+        assert torch.equal(out_g, out * gd[:, None, None, :])
+    elif sweep:
+        assert st == _lib.ISC_ERR_UNSUPPORTED  # pooling wider images needs y
+        st_g, out_g, _ = run(gd, True, False)
+        assert st_g == 0 and torch.equal(out_g, out * gd[:, None, None, :])
+    else:
+        assert st == _lib.ISC_ERR_UNSUPPORTED and st_g == _lib.ISC_ERR_UNSUPPORTED
 
 
 @pytest.mark.parametrize("b,c,s,ld1,ld2", [(5, 1536, 64, 1536, 64), (3, 256, 16, 256, 32), (1, 40, 12, 64, 32), (2, 3840, 160, 3840, 160)])
