@@ -64,7 +64,7 @@ __device__ __forceinline__ void cs_wait_vmcnt() {
 template <int ACT>
 __device__ __forceinline__ float cs_act(float v) {
     if constexpr (ACT == ISC_ACT_RELU) return fmaxf(v, 0.f);
-    if constexpr (ACT == ISC_ACT_SILU) return __fdiv_rn(v, 1.f + expf(-v));
+    if constexpr (ACT == ISC_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));  // same form as encoder.hip apply_act
     return v;
 }
 

@@ -44,8 +44,9 @@ struct ConvParams {
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ISC_ACT_RELU) return fmaxf(v, 0.f);
     if (act == ISC_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-    if (act == ISC_ACT_SILU) return __fdiv_rn(v, 1.f + expf(-v));
-    if (act == ISC_ACT_SIGMOID) return __fdiv_rn(1.f, 1.f + expf(-v));
+    // hardware exp2 / rcp (about 1 ulp each; 3e-7 relative on the result): the depthwise kernels are VALU-bound on this
+    if (act == ISC_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
+    if (act == ISC_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __expf(-v));
     return v;
 }
 
@@ -559,74 +560,118 @@ __global__ __launch_bounds__(256) void k_global_avgpool_nhwc(const float* __rest
 
 // Squeeze-excitation gate of IMG images per workgroup: gate = sigmoid(w2 . silu(w1 . pooled + b1) + b2).  As two
 // launches of the convolution kernel these are M = B-row GEMMs on two or three workgroups with a serial 48-step K loop
-// (143 + 34 us for C = 1536, S = 64, B = 512); here fc1 puts the lanes of a wave along C (coalesced 16-byte weight
-// loads, one shuffle reduction per output), fc2 gives every thread whole outputs (its own 4 S-byte weight row), the
-// squeezed vector stays in LDS and every weight load serves IMG images.
+// (143 + 34 us for C = 1536, S = 64, B = 512).  This is a latency problem (0.8 MB of L2-resident weights per workgroup),
+// so the shape is chosen for loads in flight: 16 waves; fc1 gives every wave four outputs at once with the lanes along C
+// (coalesced 16-byte weight loads, one shuffle reduction per output); fc2 puts LPR = 2^k >= S / 4 lanes along a weight
+// row, 64 / LPR rows per load instruction, four instructions in flight; the squeezed vector stays in LDS and every
+// weight load serves IMG images.
+constexpr int SE_THREADS = 1024;
 template <int IMG>
-__global__ __launch_bounds__(256) void k_se_gate(const float* __restrict__ pooled, int B, int C, const float* __restrict__ w1,
-                                                 int ld1, const float* __restrict__ b1, int S,
-                                                 const float* __restrict__ w2, int ld2, const float* __restrict__ b2,
-                                                 float* __restrict__ gate) {
+__global__ __launch_bounds__(SE_THREADS) void k_se_gate(const float* __restrict__ pooled, int B, int C,
+                                                        const float* __restrict__ w1, int ld1, const float* __restrict__ b1,
+                                                        int S, const float* __restrict__ w2, int ld2,
+                                                        const float* __restrict__ b2, int lpr, float* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(16))) float se_lds[];
     float* sx = se_lds;            // [IMG][C]
     float* sq = se_lds + IMG * C;  // [IMG][S]
+    constexpr int NW = SE_THREADS / 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int img0 = blockIdx.x * IMG;
     const int cvec = C / 4;
-    for (int i = tid; i < IMG * cvec; i += 256) {
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < IMG * cvec; i += SE_THREADS) {
         const int im = i / cvec, c4 = i - im * cvec;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 v = zero;
         if (img0 + im < B) v = *reinterpret_cast<const f32x4*>(pooled + (size_t)(img0 + im) * C + c4 * 4);
         *reinterpret_cast<f32x4*>(sx + im * C + c4 * 4) = v;
     }
     __syncthreads();
-    for (int n = wave; n < S; n += 4) {
-        float acc[IMG];
+    // fc1: outputs n0 + {0, NW, 2 NW, 3 NW} of this wave together
+    for (int n0 = wave; n0 < S; n0 += 4 * NW) {
+        float acc[4][IMG];
 #pragma unroll
-        for (int im = 0; im < IMG; ++im) acc[im] = 0.f;
-        const float* wr = w1 + (size_t)n * ld1;
-        for (int c4 = lane; c4 < cvec; c4 += 64) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c4 * 4);
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int im = 0; im < IMG; ++im) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(sx + im * C + c4 * 4);
+            for (int im = 0; im < IMG; ++im) acc[j][im] = 0.f;
+        for (int cb = lane; cb < cvec; cb += 64 * 3) {  // twelve weight loads in flight per lane
+            f32x4 wv[3][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[im] = fmaf(wv[e], xv[e], acc[im]);
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + j * NW, c4 = cb + 64 * u;
+                    wv[u][j] = (n < S && c4 < cvec) ? *reinterpret_cast<const f32x4*>(w1 + (size_t)n * ld1 + c4 * 4) : zero;
+                }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int c4 = cb + 64 * u;
+                if (c4 >= cvec) break;
+#pragma unroll
+                for (int im = 0; im < IMG; ++im) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(sx + im * C + c4 * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[j][im] = fmaf(wv[u][j][e], xv[e], acc[j][im]);
+                }
             }
         }
 #pragma unroll
-        for (int im = 0; im < IMG; ++im) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) acc[im] += __shfl_xor(acc[im], off, 64);
-        }
+            for (int im = 0; im < IMG; ++im)
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) acc[j][im] += __shfl_xor(acc[j][im], off, 64);
         if (lane == 0) {
-            const float bias = b1 ? b1[n] : 0.f;
 #pragma unroll
-            for (int im = 0; im < IMG; ++im) sq[im * S + n] = apply_act(acc[im] + bias, ISC_ACT_SILU);
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + j * NW;
+                if (n >= S) continue;
+                const float bias = b1 ? b1[n] : 0.f;
+#pragma unroll
+                for (int im = 0; im < IMG; ++im) sq[im * S + n] = apply_act(acc[j][im] + bias, ISC_ACT_SILU);
+            }
         }
     }
     __syncthreads();
+    // fc2: lane = (row r of the load, 16-byte piece s4 of the row)
     const int svec = S / 4;
-    for (int c = tid; c < C; c += 256) {
-        float acc[IMG];
+    const int rpl = 64 / lpr;
+    const int r = lane / lpr;
+    const int s4 = lane - r * lpr;
+    const bool s_ok = s4 < svec;
+    f32x4 qv[IMG];
 #pragma unroll
-        for (int im = 0; im < IMG; ++im) acc[im] = 0.f;
-        const float* wr = w2 + (size_t)c * ld2;
-        for (int s4 = 0; s4 < svec; ++s4) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + s4 * 4);
+    for (int im = 0; im < IMG; ++im) qv[im] = s_ok ? *reinterpret_cast<const f32x4*>(sq + im * S + s4 * 4) : zero;
+    const int step = NW * rpl;  // rows per round of the workgroup
+    constexpr int NR = 8;  // weight loads in flight per lane
+    for (int c0 = wave * rpl + r; c0 < C + (NR - 1) * step; c0 += NR * step) {
+        f32x4 wv[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int c = c0 + j * step;
+            wv[j] = (s_ok && c < C) ? *reinterpret_cast<const f32x4*>(w2 + (size_t)c * ld2 + s4 * 4) : zero;
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int c = c0 + j * step;
+            float acc[IMG];
 #pragma unroll
             for (int im = 0; im < IMG; ++im) {
-                const f32x4 qv = *reinterpret_cast<const f32x4*>(sq + im * S + s4 * 4);
+                acc[im] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[im] = fmaf(wv[e], qv[e], acc[im]);
+                for (int e = 0; e < 4; ++e) acc[im] = fmaf(wv[j][e], qv[im][e], acc[im]);
+                for (int off = lpr >> 1; off >= 1; off >>= 1) acc[im] += __shfl_xor(acc[im], off, 64);
+            }
+            if (s4 == 0 && c < C) {
+                const float bias = b2 ? b2[c] : 0.f;
+#pragma unroll
+                for (int im = 0; im < IMG; ++im)
+                    if (img0 + im < B) gate[(size_t)(img0 + im) * C + c] = apply_act(acc[im] + bias, ISC_ACT_SIGMOID);
             }
         }
-        const float bias = b2 ? b2[c] : 0.f;
-#pragma unroll
-        for (int im = 0; im < IMG; ++im)
-            if (img0 + im < B) gate[(size_t)(img0 + im) * C + c] = apply_act(acc[im] + bias, ISC_ACT_SIGMOID);
     }
 }
 
@@ -850,11 +895,13 @@ extern "C" int isc_se_gate(const float* pooled, int B, int C, const float* w1, i
     ISC_REQUIRE(pooled && w1 && w2 && gate && B > 0 && C > 0 && S > 0 && ld1 >= C && ld2 >= S);
     if (C % 4 != 0 || S % 4 != 0 || ld1 % 4 != 0 || ld2 % 4 != 0) return ISC_ERR_UNSUPPORTED;
     if (!isc_aligned(pooled, 16) || !isc_aligned(w1, 16) || !isc_aligned(w2, 16)) return ISC_ERR_ALIGNMENT;
-    constexpr int IMG = 2;
+    constexpr int IMG = 2;  // measured: 1 -> 54 us, 2 -> 45 us, 4 -> 72 us per launch at C = 1536, S = 64, B = 512
     const size_t lds = (size_t)IMG * ((size_t)C + S) * sizeof(float);
-    if (lds > 64 * 1024) return ISC_ERR_UNSUPPORTED;  // C + S <= 8192
-    hipLaunchKernelGGL((k_se_gate<IMG>), dim3((unsigned)isc_ceil_div(B, IMG)), dim3(256), lds, isc_stream(stream), pooled, B,
-                       C, w1, ld1, b1, S, w2, ld2, b2, gate);
+    if (lds > 64 * 1024 || S > 256) return ISC_ERR_UNSUPPORTED;  // C + S <= 16384, S <= 256
+    int lpr = 1;
+    while (lpr < S / 4) lpr *= 2;  // lanes along a w2 row
+    hipLaunchKernelGGL((k_se_gate<IMG>), dim3((unsigned)isc_ceil_div(B, IMG)), dim3(SE_THREADS), lds, isc_stream(stream),
+                       pooled, B, C, w1, ld1, b1, S, w2, ld2, b2, lpr, gate);
     return isc_launch_status();
 }
 

@@ -179,7 +179,7 @@ int isc_dwconv2d_nhwc_pool(const float* x, int B, int H, int W, int C, const flo
  * `SqueezeExcitation` (fc1, SiLU, fc2, Sigmoid on the pooled map) inside the MBConv blocks the reference runs through
  * src/imagescry/models/embedding.py:133-147.  pooled float [B, C]; w1 float [S, ld1] (row stride ld1 >= C floats),
  * b1 float [S] or NULL; w2 float [C, ld2] (ld2 >= S), b2 float [C] or NULL; C, S, ld1, ld2 multiples of 4,
- * C + S <= 8192. */
+ * C + S <= 16384, S <= 256. */
 int isc_se_gate(const float* pooled, int B, int C, const float* w1, int ld1, const float* b1, int S, const float* w2,
                 int ld2, const float* b2, float* gate, void* stream);
 

@@ -29,29 +29,33 @@ for si, blocks in enumerate(E.block_specs("s"), 1):
                 layers.append((f"{n} project", "conv", pout, b.expanded, b.cout, (pout * b.expanded + pout * b.cout) * 4 + res))
         else:
             layers.append((f"{n} expand", "conv", pin, b.cin, b.expanded, (pin * b.cin + pin * b.expanded) * 4))
-            layers.append((f"{n} dw 3x3/{b.stride}", "dw", pout, 9, b.expanded, (pin + pout) * b.expanded * 4))
-            if b.stride != 1:
+            if b.stride == 1 and h <= 14:  # two sweeps of the depthwise kernel, plain projection
+                layers.append((f"{n} dw pool", "dw", pout, 9, b.expanded, pin * b.expanded * 4))
+                layers.append((f"{n} se gate", "se", B, b.expanded, 2 * b.squeeze, 0))
+                layers.append((f"{n} dw gated", "dw", pout, 9, b.expanded, (pin + pout) * b.expanded * 4))
+                layers.append((f"{n} project", "conv", pout, b.expanded, b.cout, (pout * b.expanded + pout * b.cout) * 4 + res))
+            else:
+                layers.append((f"{n} dw 3x3/{b.stride}", "dw", pout, 9, b.expanded, (pin + pout) * b.expanded * 4))
                 layers.append((f"{n} avgpool", "pool", pout, 1, b.expanded, pout * b.expanded * 4))
-            layers.append((f"{n} se fc1", "conv", B, b.expanded, b.squeeze, 0))
-            layers.append((f"{n} se fc2", "conv", B, b.squeeze, b.expanded, 0))
-            layers.append((f"{n} gated project", "conv", pout, b.expanded, b.cout, (pout * b.expanded + pout * b.cout) * 4 + res))
+                layers.append((f"{n} se gate", "se", B, b.expanded, 2 * b.squeeze, 0))
+                layers.append((f"{n} gated project", "conv", pout, b.expanded, b.cout, (pout * b.expanded + pout * b.cout) * 4 + res))
         h = h2
 layers.append(("head 1x1", "conv", B * h * h, 256, 1280, B * h * h * (256 + 1280) * 4))
 f = max(glob.glob("gpurun_out/prof_eff_layers/*/*kernel_trace.csv"), key=os.path.getmtime)
-pat = {"conv": ("k_conv_f32", "k_conv1x1_f32_stream"), "dw": ("k_dwconv",), "pool": ("k_global_avgpool",)}
+pat = {"conv": ("k_conv_f32", "k_conv1x1_f32_stream"), "dw": ("k_dwconv",), "pool": ("k_global_avgpool",), "se": ("k_se_gate",)}
 rows = [r for r in csv.DictReader(open(f)) if any(p in r["Kernel_Name"] for ps in pat.values() for p in ps)]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 last = rows[-len(layers):]
 print(f"{'layer':24s} {'M':>9s} {'K':>5s} {'N':>5s} {'us':>8s} {'TFLOP/s':>8s} {'of peak':>7s} {'GB/s':>7s}  kernel")
 agg = {}
-tot = {"conv": [0, 0], "dw": [0, 0], "pool": [0, 0]}
+tot = {"conv": [0, 0], "dw": [0, 0], "pool": [0, 0], "se": [0, 0]}
 for (name, kind, m, k, n, by), r in zip(layers, last):
     kn = r["Kernel_Name"]
     assert any(p in kn for p in pat[kind]), (name, kn)
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     fl = 2.0 * m * k * n
     tot[kind][0] += us; tot[kind][1] += fl
-    short = kn.split("::")[-1].split("(")[0][:34]
+    short = kn.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:40]
     print(f"{name:24s} {m:9d} {k:5d} {n:5d} {us:8.1f} {fl/us/1e6:8.1f} {fl/us/1e6/157.3:7.2f} {by/us/1e3:7.0f}  {short}")
     key = name.split(" ", 1)[0][:2] + " " + name.split(" ", 1)[1].split("/")[0]
     a = agg.setdefault(key, [0, 0, 0]); a[0] += us; a[1] += fl; a[2] += 1
