@@ -60,7 +60,8 @@ __device__ __forceinline__ void conv_dma16(const void* gsrc, unsigned char* lds_
 #define CONV_DS_READ(dst_, addr_, off_) \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_))
 
-// TCO output channels x TPIX pixels per workgroup of 4 waves; every wave owns a 64 x 64 sub-tile.
+// TCO output channels x TPIX pixels per workgroup of 4 waves; every wave owns a 64 x 64 sub-tile (32 x 64 in the
+// 32-channel tile, for layers with at most 32 output channels: EfficientNetV2's 24-channel stem and first stage).
 // TAP4 = packed-K mode, for Cin % 32 != 0 (Cin % 4 == 0): the reduction axis k = (r * S + s) * Cin + c is cut into
 // 128-byte K steps regardless of tap boundaries -- every lane's 16-byte chunk (4 channels) finds its own filter tap --
 // and weights are [Cout][ceil(R*S*Cin / 32) * 32] with the tail zero.  Cin == 4 (the stem: RGB + one zero channel) is
@@ -71,7 +72,8 @@ __device__ __forceinline__ void conv_dma16(const void* gsrc, unsigned char* lds_
 // drain the DMA in flight before it).  Used whenever no per-element transform of x is asked for (`sub`, `scale`).
 template <int TCO, int TPIX, bool TAP4, bool DMA>
 __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
-    constexpr int WCO = TCO / 64;          // waves along the output channels
+    constexpr int WCO = TCO >= 64 ? TCO / 64 : 1;  // waves along the output channels
+    constexpr int MI = TCO / WCO / 16;             // 16-channel blocks per wave: 4, or 2 for the 32-channel tile
     constexpr int NA = TCO * 8 / 256;      // 16-byte staging slots per thread, weight tile
     constexpr int NB = TPIX * 8 / 256;     // ... pixel tile
     constexpr int A_BYTES = TCO * 128;
@@ -129,13 +131,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
     // The accumulators start as bias + residual (issued first, so these loads fly while the first K step is staged):
     // the epilogue is then only the activation and the store.  16x16 MFMA result layout: column (pixel) = lane & 15,
     // rows (channels) = 4 * (lane >> 4) + 0..3.
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const int m = pix0 + wpix * 64 + ni * 16 + (lane & 15);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int co = co0 + wco * 64 + mi * 16 + (lane >> 4) * 4;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int co = co0 + wco * (MI * 16) + mi * 16 + (lane >> 4) * 4;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (m < p.M && co < p.Cout) {
                 if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + co);
@@ -254,40 +256,50 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
         for (int ks = 0; ks < p.ksteps; ++ks) {
             const int buf = ks & 1;
             if (ks + 1 < p.ksteps) dma_step(ks + 1, buf ^ 1);
-            const unsigned a_img = lds_addr + buf * BUF_BYTES + wco * 64 * 128;
+            const unsigned a_img = lds_addr + buf * BUF_BYTES + wco * (MI * 16) * 128;
             const unsigned b_img = lds_addr + buf * BUF_BYTES + A_BYTES + wpix * 64 * 128;
-            u32x4 a[2][4], b[2][4];
+            u32x4 a[2][MI], b[2][4];
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 CONV_DS_READ(a[cc][0], a_img + foff[cc], 0);
                 CONV_DS_READ(a[cc][1], a_img + foff[cc], 2048);
-                CONV_DS_READ(a[cc][2], a_img + foff[cc], 4096);
-                CONV_DS_READ(a[cc][3], a_img + foff[cc], 6144);
+                if constexpr (MI == 4) {
+                    CONV_DS_READ(a[cc][2], a_img + foff[cc], 4096);
+                    CONV_DS_READ(a[cc][3], a_img + foff[cc], 6144);
+                }
                 CONV_DS_READ(b[cc][0], b_img + foff[cc], 0);
                 CONV_DS_READ(b[cc][1], b_img + foff[cc], 2048);
                 CONV_DS_READ(b[cc][2], b_img + foff[cc], 4096);
                 CONV_DS_READ(b[cc][3], b_img + foff[cc], 6144);
             }
-            asm volatile("s_waitcnt lgkmcnt(8)"
-                         : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]), "+v"(b[0][1]),
-                           "+v"(b[0][2]), "+v"(b[0][3]));
+            if constexpr (MI == 4)
+                asm volatile("s_waitcnt lgkmcnt(8)"
+                             : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]), "+v"(b[0][1]),
+                               "+v"(b[0][2]), "+v"(b[0][3]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(6)"
+                             : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[0][mi][j]),
                                                                            __uint_as_float(b[0][ni][j]), acc[mi][ni], 0, 0, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[1][0]), "+v"(b[1][1]),
-                           "+v"(b[1][2]), "+v"(b[1][3]));
+            if constexpr (MI == 4)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[1][0]), "+v"(b[1][1]),
+                               "+v"(b[1][2]), "+v"(b[1][3]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[1][mi][j]),
@@ -307,20 +319,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
         const bool more = ks + 1 < p.ksteps;
         if (more) load_step(ks + 1);
 
-        const unsigned char* a_img = lds + buf * BUF_BYTES + wco * 64 * 128;
+        const unsigned char* a_img = lds + buf * BUF_BYTES + wco * (MI * 16) * 128;
         const unsigned char* b_img = lds + buf * BUF_BYTES + A_BYTES + wpix * 64 * 128;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-            u32x4 a[4], b[4];
+            u32x4 a[MI], b[4];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const u32x4*>(a_img + mi * 2048 + foff[cc]);
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const u32x4*>(a_img + mi * 2048 + foff[cc]);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const u32x4*>(b_img + ni * 2048 + foff[cc]);
             // element j of every lane's chunk feeds the j-th MFMA: a K-axis permutation shared by both operands
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[mi][j]),
@@ -337,8 +349,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
         const int m = pix0 + wpix * 64 + ni * 16 + frow;
         if (m >= p.M) continue;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int co = co0 + wco * 64 + mi * 16 + fg * 4;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int co = co0 + wco * (MI * 16) + mi * 16 + fg * 4;
             if (co >= p.Cout) continue;  // Cout % 4 == 0, so a lane's four channels are in or out together
             f32x4 v = acc[mi][ni];
 #pragma unroll
@@ -745,6 +757,15 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     // 64-channel tiles wherever they pad Cout less than 128-channel ones do (Cout <= 64, but also 160 -> 192 instead of
     // 256, 192 -> 192 instead of 256): the wasted quarter of the matrix work is worth more than the extra tile reloads
     const bool narrow = isc_ceil_div(Cout, 64) * 64 < isc_ceil_div(Cout, 128) * 128;
+    if (Cout <= 32 && !sub && !scale && !conv_no_dma()) {  // half the matrix work of the 64-channel tile
+        const int64_t nb = isc_ceil_div<int64_t>(M, 256);
+        if (nb > 0x7fffffff) return ISC_ERR_UNSUPPORTED;
+        isc_timing_begin(ISC_KERNEL_CONV, s);
+        if (tap4) hipLaunchKernelGGL((k_conv_f32<32, 256, true, true>), dim3((unsigned)nb), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_conv_f32<32, 256, false, true>), dim3((unsigned)nb), dim3(256), 0, s, p);
+        isc_timing_end(ISC_KERNEL_CONV, s);
+        return isc_launch_status();
+    }
     const int64_t blocks = narrow ? isc_ceil_div(Cout, 64) * isc_ceil_div<int64_t>(M, 256)
                                   : isc_ceil_div(Cout, 128) * isc_ceil_div<int64_t>(M, 128);
     if (blocks > 0x7fffffff) return ISC_ERR_UNSUPPORTED;

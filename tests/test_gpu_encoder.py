@@ -39,6 +39,8 @@ def _rel_err(got: torch.Tensor, exp: torch.Tensor) -> float:
         (5, 1, 1, 2048, 768, 1, 1, 0),  # the projection head as a 1x1 conv
         (1, 7, 7, 160, 64, 1, 1, 0),  # stem GEMM over im2col rows
         (1, 10, 10, 32, 100, 5, 1, 2),  # Cout not a tile multiple, 5x5
+        (2, 13, 12, 64, 24, 1, 1, 0),  # Cout <= 32: the 32-channel tile, eight channels of it past Cout
+        (3, 17, 17, 32, 32, 3, 1, 1),  # ... all 32 used, ragged pixel tile
         # large enough for the streaming 1 x 1 kernel (conv1x1_stream.hip): ragged last pixel tile, 1 / 2 / 4 channel blocks
         (8, 130, 130, 64, 256, 1, 1, 0),  # ResNet layer1 expand: two K steps per tile
         (4, 129, 129, 256, 512, 1, 1, 0),
