@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void k_dwconv_nhwc(const float* __restrict__ x
 }
 
 // Depthwise 3 x 3, stride 1, pad 1 -- the MBConv case -- as a row sweep: one thread = four channels of a strip of TW
-// output columns, walking down the image with the three input rows of the window in registers, so every input element
+// output columns, walking down the image with the three input rows of the window (and the next one, in flight) in registers, so every input element
 // is loaded once per strip ((TW + 2) / TW loads per output instead of nine; the nine-fold re-read of k_dwconv_nhwc goes
 // through the L2 and is what bounds it).  Lanes = consecutive channel vectors of one pixel: each load / store
 // instruction of a wave is one contiguous 1 KiB.  POOL: also the mean over the image of the activated output (the
@@ -469,7 +469,9 @@ __global__ __launch_bounds__(256) void k_dwconv_nhwc(const float* __restrict__ x
 // MBConv block runs the kernel twice -- pooled mean, k_se_gate, then y = act(dw) * gate -- so that its 1 x 1 projection is
 // a plain convolution (the gate applied while staging the projection's input doubled that convolution's time; the
 // second read of x here costs a quarter of that).
-template <int TW, bool WRITE, bool POOL, bool GATE>
+// SILU: the activation is known to be SiLU (every MBConv block); otherwise `act` is looked at per element, which costs
+// this kernel a quarter of its time in scalar branches.
+template <int TW, bool WRITE, bool POOL, bool GATE, bool SILU>
 __global__ __launch_bounds__(256) void k_dwconv3x3_rows(const float* __restrict__ x, int H, int W, int C,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         int act, int strips, size_t total, const float* __restrict__ gate,
@@ -503,9 +505,10 @@ __global__ __launch_bounds__(256) void k_dwconv3x3_rows(const float* __restrict_
         }
     };
     f32x4 sum = zero;
-    // rows a, b2 hold input rows ho - 1 and ho; c receives row ho + 1; then output row ho
-    auto step = [&](f32x4 (&a)[TW + 2], f32x4 (&b2)[TW + 2], f32x4 (&c)[TW + 2], int ho) {
-        load_row(ho + 1, c);
+    // rows a, b2, c hold input rows ho - 1, ho, ho + 1; d receives row ho + 2 (in flight under this row's arithmetic);
+    // then output row ho
+    auto step = [&](f32x4 (&a)[TW + 2], f32x4 (&b2)[TW + 2], f32x4 (&c)[TW + 2], f32x4 (&d)[TW + 2], int ho) {
+        load_row(ho + 2, d);
 #pragma unroll
         for (int j = 0; j < TW; ++j) {
             if (w0 + j >= W) break;
@@ -532,21 +535,23 @@ __global__ __launch_bounds__(256) void k_dwconv3x3_rows(const float* __restrict_
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = apply_act(acc[e], act);
+            for (int e = 0; e < 4; ++e) acc[e] = apply_act(acc[e], SILU ? (int)ISC_ACT_SILU : act);
             if (POOL) sum += acc;
             if (GATE) acc *= gv;
             if (WRITE) *reinterpret_cast<f32x4*>(yb + ((size_t)ho * W + w0 + j) * C) = acc;
         }
     };
 
-    f32x4 r0[TW + 2], r1[TW + 2], r2[TW + 2];
+    f32x4 r0[TW + 2], r1[TW + 2], r2[TW + 2], r3[TW + 2];
 #pragma unroll
     for (int j = 0; j < TW + 2; ++j) r0[j] = zero;  // row -1
     load_row(0, r1);
-    for (int ho = 0; ho < H; ho += 3) {
-        step(r0, r1, r2, ho);
-        if (ho + 1 < H) step(r1, r2, r0, ho + 1);
-        if (ho + 2 < H) step(r2, r0, r1, ho + 2);
+    load_row(1, r2);
+    for (int ho = 0; ho < H; ho += 4) {
+        step(r0, r1, r2, r3, ho);
+        if (ho + 1 < H) step(r1, r2, r3, r0, ho + 1);
+        if (ho + 2 < H) step(r2, r3, r0, r1, ho + 2);
+        if (ho + 3 < H) step(r3, r0, r1, r2, ho + 3);
     }
     if (POOL) {
         float* pp = pooled + b * C + cv * 4;
@@ -892,9 +897,15 @@ extern "C" int isc_dwconv2d_nhwc_pool(const float* x, int B, int H, int W, int C
             return ISC_ERR_LAUNCH;
         const dim3 grid((unsigned)blocks), block(256);
         const float inv_hw = 1.f / (float)(H * W);
-#define ISC_DW_ROWS(WRITE_, POOL_, GATE_)                                                                               \
-    hipLaunchKernelGGL((k_dwconv3x3_rows<TW, WRITE_, POOL_, GATE_>), grid, block, 0, s, x, H, W, C, w, bias, act, strips, \
-                       total, gate, y, pooled, inv_hw)
+#define ISC_DW_ROWS(WRITE_, POOL_, GATE_)                                                                            \
+    do {                                                                                                             \
+        if (act == ISC_ACT_SILU)                                                                                     \
+            hipLaunchKernelGGL((k_dwconv3x3_rows<TW, WRITE_, POOL_, GATE_, true>), grid, block, 0, s, x, H, W, C, w, \
+                               bias, act, strips, total, gate, y, pooled, inv_hw);                                   \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_dwconv3x3_rows<TW, WRITE_, POOL_, GATE_, false>), grid, block, 0, s, x, H, W, C, w, \
+                               bias, act, strips, total, gate, y, pooled, inv_hw);                                   \
+    } while (0)
         if (!y) ISC_DW_ROWS(false, true, false);
         else if (pooled && gate) ISC_DW_ROWS(true, true, true);
         else if (pooled) ISC_DW_ROWS(true, true, false);

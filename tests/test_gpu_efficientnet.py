@@ -133,6 +133,32 @@ def test_depthwise_with_pooled_mean(b, h, w, c, k, stride, device: torch.device)
         assert st == _lib.ISC_ERR_UNSUPPORTED and st_g == _lib.ISC_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("act_name", ["none", "relu", "gelu", "sigmoid"])
+def test_depthwise_sweep_other_activations(act_name: str, device: torch.device) -> None:
+    """The row-sweep depthwise kernel is specialised for SiLU; every other activation takes its generic instantiation."""
+    from imagescry_amd import _lib
+
+    lib = _lib.load()
+    act, fn = {"none": (_lib.ISC_ACT_NONE, lambda v: v), "relu": (_lib.ISC_ACT_RELU, F.relu),
+               "gelu": (_lib.ISC_ACT_GELU, F.gelu), "sigmoid": (_lib.ISC_ACT_SIGMOID, torch.sigmoid)}[act_name]
+    g = cases.gen(5)
+    b, c, h, w = 2, 32, 9, 11
+    x = torch.randn(b, c, h, w, generator=g)
+    wt = torch.randn(c, 1, 3, 3, generator=g) * 0.3
+    bias = torch.randn(c, generator=g)
+    exp = fn(F.conv2d(x, wt, bias, padding=1, groups=c))
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device)
+    wd = wt[:, 0].permute(1, 2, 0).contiguous().to(device)
+    bd = bias.to(device)
+    out = torch.empty((b, h, w, c), device=device)
+    pooled = torch.empty((b, c), device=device)
+    st = lib.isc_dwconv2d_nhwc_pool(xd.data_ptr(), b, h, w, c, wd.data_ptr(), 3, 1, 1, bd.data_ptr(), act, None,
+                                    out.data_ptr(), pooled.data_ptr(), _lib.stream_handle(device))
+    _lib.check(st, "isc_dwconv2d_nhwc_pool")
+    np.testing.assert_allclose(out.permute(0, 3, 1, 2).cpu().numpy(), exp.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pooled.cpu().numpy(), exp.mean(dim=(2, 3)).numpy(), rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("b,c,s,ld1,ld2", [(5, 1536, 64, 1536, 64), (3, 256, 16, 256, 32), (1, 40, 12, 64, 32), (2, 3840, 160, 3840, 160)])
 def test_se_gate(b, c, s, ld1, ld2, device: torch.device) -> None:
     """isc_se_gate against torch: sigmoid(fc2(silu(fc1(pooled)))), weight rows with a stride wider than the row."""
