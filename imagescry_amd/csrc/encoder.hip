@@ -50,6 +50,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+template <int V>
+struct IntTag {
+    static constexpr int value = V;
+};
+
 // a 128-byte line of zeros: the LDS-DMA source of filter taps outside the image
 __device__ __attribute__((aligned(128))) const float g_zero_line[32] = {0.f};
 
@@ -209,16 +214,27 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
 
     // LDS-DMA form of load_step + store_step: this thread's slots of K step ks straight into buffer buf.  Wave w's 64
     // lanes cover rows 8 w .. 8 w + 7 of a staging round (lane-linear 1 KiB), round i is 32 rows (4 KiB) further.
+    // packed-K cursor of this lane's chunk (see dma_step): filter tap (pk_r, pk_s), 16-byte piece pk_c4 of its channels
+    int pk_r = 0, pk_s = 0, pk_c4 = 0;
+    if constexpr (TAP4 && DMA) {
+        const int tap0 = lchunk / p.cin4;
+        pk_c4 = lchunk - tap0 * p.cin4;
+        pk_r = tap0 / p.S;
+        pk_s = tap0 - pk_r * p.S;
+    }
     auto dma_step = [&](int ks, int buf) {
         unsigned char* a = lds + buf * BUF_BYTES + (tid >> 6) * 1024;
         unsigned char* b = a + A_BYTES;
         if constexpr (TAP4) {
-            const int kc = ks * 8 + lchunk;
-            const int tap = kc / p.cin4;
-            const int c4 = kc - tap * p.cin4;
-            const int r = tap / p.S;
-            const int s = tap - r * p.S;
-            const bool tap_ok = tap < p.R * p.S;
+            // this lane's chunk kc = 8 ks + lchunk of the flattened (tap, channel / 4) axis, kept as (r, s, c4) and
+            // advanced by 8 chunks per call (dma_step runs for ks = 0, 1, 2, ... in order) instead of divided out
+            const int r = pk_r, s = pk_s, c4 = pk_c4;
+            const bool tap_ok = r < p.R;
+            pk_c4 += 8;
+            while (pk_c4 >= p.cin4) {
+                pk_c4 -= p.cin4;
+                if (++pk_s == p.S) { pk_s = 0; ++pk_r; }
+            }
 #pragma unroll
             for (int i = 0; i < NA; ++i) conv_dma16(p.w + (size_t)(a_off[i] + ks * 32), a + 4096 * i);
 #pragma unroll
@@ -343,22 +359,30 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
     }
     }
 
-    // ---- epilogue: activation and one 16-byte store per (pixel, four channels)
+    // ---- epilogue: activation and one 16-byte store per (pixel, four channels).  The activation is chosen ONCE, outside
+    // the element loops (looked at per element, the switch is a tenth of a short-K tile's time in scalar branches).
+    auto epilogue = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int m = pix0 + wpix * 64 + ni * 16 + frow;
-        if (m >= p.M) continue;
+        for (int ni = 0; ni < 4; ++ni) {
+            const int m = pix0 + wpix * 64 + ni * 16 + frow;
+            if (m >= p.M) continue;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int co = co0 + wco * (MI * 16) + mi * 16 + fg * 4;
-            if (co >= p.Cout) continue;  // Cout % 4 == 0, so a lane's four channels are in or out together
-            f32x4 v = acc[mi][ni];
+            for (int mi = 0; mi < MI; ++mi) {
+                const int co = co0 + wco * (MI * 16) + mi * 16 + fg * 4;
+                if (co >= p.Cout) continue;  // Cout % 4 == 0, so a lane's four channels are in or out together
+                f32x4 v = acc[mi][ni];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
-            if (p.res && p.res_after_act) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
-            *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.Cout + co) = v;
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], ACT < 0 ? p.act : ACT);
+                if (p.res && p.res_after_act) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
+                *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.Cout + co) = v;
+            }
         }
-    }
+    };
+    if (p.act == ISC_ACT_NONE) epilogue(IntTag<ISC_ACT_NONE>{});
+    else if (p.act == ISC_ACT_RELU) epilogue(IntTag<ISC_ACT_RELU>{});
+    else if (p.act == ISC_ACT_SILU) epilogue(IntTag<ISC_ACT_SILU>{});
+    else epilogue(IntTag<-1>{});
 }
 
 __global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ x, int C, int HW, int Cpad, size_t total,
