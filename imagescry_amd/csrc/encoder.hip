@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (m < p.M && co < p.Cout) {
                 if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + co);
-                if (p.res && !p.res_after_act) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
+                if (!DMA && p.res && !p.res_after_act)
+                    v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
             }
             acc[mi][ni] = v;
         }
@@ -264,14 +265,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
         }
     };
 
+    f32x4 rv[MI][4];  // residual tile (LDS-DMA path: loaded during the last K step)
     if constexpr (DMA) {
         dma_step(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // also the bias / residual loads of the accumulators
         __builtin_amdgcn_s_barrier();
         const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-        for (int ks = 0; ks < p.ksteps; ++ks) {
-            const int buf = ks & 1;
-            if (ks + 1 < p.ksteps) dma_step(ks + 1, buf ^ 1);
+        // one K step of matrix work out of buffer buf (fragment reads in asm, see above)
+        auto k_step = [&](int buf) {
             const unsigned a_img = lds_addr + buf * BUF_BYTES + wco * (MI * 16) * 128;
             const unsigned b_img = lds_addr + buf * BUF_BYTES + A_BYTES + wpix * 64 * 128;
             u32x4 a[2][MI], b[2][4];
@@ -320,11 +321,42 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
                     for (int ni = 0; ni < 4; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[1][mi][j]),
                                                                            __uint_as_float(b[1][ni][j]), acc[mi][ni], 0, 0, 0);
+        };
+        auto step_end = [&]() {
             // the next K step has landed (its DMA flew under this step's 128 MFMAs); everyone is done reading this buffer
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+        };
+        // The residual tile is fetched under the LAST K step and added in the epilogue.  (As part of the accumulators'
+        // initial value its latency sat in front of the first MFMA of every tile: measured on 14 x 14 x 256 -> 1024,
+        // B = 512: 676 us with the residual, 546 without -- the whole read, un-overlapped; now 632.  Fetching it one
+        // step earlier still needs more registers than there are: 160-200 bytes of scratch and a slower network.)
+        auto fetch_residual = [&]() {
+            if (!p.res) return;
+            // 32-bit element offsets from the uniform base (M * Cout < 2^31, checked by the host): one VGPR per pixel row,
+            // the channel blocks are immediate offsets
+            const int cob = co0 + wco * (MI * 16) + (lane >> 4) * 4;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int m = pix0 + wpix * 64 + ni * 16 + (lane & 15);
+                const unsigned off = (unsigned)min(m, p.M - 1) * (unsigned)p.Cout + (unsigned)cob;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    // rows past M read row M - 1, channel blocks past Cout read the last whole block: never stored
+                    const unsigned o = cob + mi * 16 < p.Cout ? off + mi * 16 : (unsigned)min(m, p.M - 1) * (unsigned)p.Cout + (unsigned)(p.Cout - 4);
+                    rv[mi][ni] = *reinterpret_cast<const f32x4*>(p.res + o);
+                }
+            }
+        };
+        for (int ks = 0; ks + 1 < p.ksteps; ++ks) {
+            const int buf = ks & 1;
+            dma_step(ks + 1, buf ^ 1);
+            k_step(buf);
+            step_end();
         }
+        fetch_residual();
+        k_step((p.ksteps - 1) & 1);
     } else {
     load_step(0);
     store_step(0);
@@ -372,9 +404,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
                 const int co = co0 + wco * (MI * 16) + mi * 16 + fg * 4;
                 if (co >= p.Cout) continue;  // Cout % 4 == 0, so a lane's four channels are in or out together
                 f32x4 v = acc[mi][ni];
+                if (DMA && p.res && !p.res_after_act) v += rv[mi][ni];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], ACT < 0 ? p.act : ACT);
-                if (p.res && p.res_after_act) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
+                if (p.res && p.res_after_act) {
+                    if (DMA) v += rv[mi][ni];
+                    else v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
+                }
                 *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.Cout + co) = v;
             }
         }
@@ -724,8 +760,6 @@ int stream_grid(size_t items) {
 
 }  // namespace
 
-int isc_conv1x1_stream_launch(const float* x, long long M, int K, const float* w, int N, const float* bias,
-                              const float* residual, int act, int res_after_act, float* out, hipStream_t stream);
 #ifdef ISC_ABLATION
 static bool conv_no_dma() {
     static const bool v = getenv("ISC_CONV_NO_DMA") != nullptr;  // A/B aid: register-staged operands everywhere
@@ -733,14 +767,6 @@ static bool conv_no_dma() {
 }
 #else
 static constexpr bool conv_no_dma() { return false; }
-#endif
-#ifdef ISC_ABLATION
-static bool conv_no_stream() {
-    static const bool v = getenv("ISC_CONV_NO_STREAM") != nullptr;  // A/B aid
-    return v;
-}
-#else
-static constexpr bool conv_no_stream() { return false; }
 #endif
 
 static int conv_launch(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S, int stride,
@@ -771,18 +797,6 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = tap4 ? 1 : Cin / 32; p.cin4 = Cin / 4; p.ksteps = ksteps; p.act = act; p.res_after_act = res_after_act;
     hipStream_t s = isc_stream(stream);
-    // 1 x 1, stride 1, whole 256-channel output blocks, a residual, at most four K steps, enough pixel tiles to fill the
-    // chip (ResNet-50 layer1 / layer2 expand convolutions): the streaming kernel of conv1x1_stream.hip, +6 % there.
-    // Measured per layer (scripts/trace_encode_layers.sh): 1088 vs 1170 us (K = 64), 769 vs 820 us (K = 128); from
-    // K = 256 on and without a residual the implicit-GEMM kernel below is as fast or faster, so it keeps those.
-    if (R == 1 && S == 1 && stride == 1 && pad == 0 && !tap4 && !sub && !scale && Cout % 256 == 0 && residual && Cin <= 128 &&
-        (act == ISC_ACT_NONE || act == ISC_ACT_RELU || act == ISC_ACT_SILU) && !conv_no_stream() &&
-        isc_ceil_div<int64_t>(M, 256) * (Cout / 256) >= 512) {
-        isc_timing_begin(ISC_KERNEL_CONV, s);
-        const int st = isc_conv1x1_stream_launch(x, M, Cin, w, Cout, bias, residual, act, res_after_act, out, s);
-        isc_timing_end(ISC_KERNEL_CONV, s);
-        return st;
-    }
     // 64-channel tiles wherever they pad Cout less than 128-channel ones do (Cout <= 64, but also 160 -> 192 instead of
     // 256, 192 -> 192 instead of 256): the wasted quarter of the matrix work is worth more than the extra tile reloads
     const bool narrow = isc_ceil_div(Cout, 64) * 64 < isc_ceil_div(Cout, 128) * 128;

@@ -41,7 +41,7 @@ def _rel_err(got: torch.Tensor, exp: torch.Tensor) -> float:
         (1, 10, 10, 32, 100, 5, 1, 2),  # Cout not a tile multiple, 5x5
         (2, 13, 12, 64, 24, 1, 1, 0),  # Cout <= 32: the 32-channel tile, eight channels of it past Cout
         (3, 17, 17, 32, 32, 3, 1, 1),  # ... all 32 used, ragged pixel tile
-        # large enough for the streaming 1 x 1 kernel (conv1x1_stream.hip): ragged last pixel tile, 1 / 2 / 4 channel blocks
+        # large 1 x 1 layers with short K loops: ragged last pixel tile, 1 / 2 / 4 channel blocks of 256
         (8, 130, 130, 64, 256, 1, 1, 0),  # ResNet layer1 expand: two K steps per tile
         (4, 129, 129, 256, 512, 1, 1, 0),
         (2, 200, 200, 32, 1024, 1, 1, 0),  # ONE K step per tile
@@ -76,8 +76,8 @@ def test_conv2d_nhwc(b, h, w, cin, cout, k, stride, pad, epilogue, device: torch
     assert _rel_err(got, exp) < 1e-5
 
 
-def test_conv1x1_stream_silu_and_residual_after_activation(device: torch.device) -> None:
-    """The streaming 1 x 1 kernel with the EfficientNetV2 epilogues: SiLU, and `act(conv + bias) + residual`."""
+def test_conv1x1_silu_and_residual_after_activation(device: torch.device) -> None:
+    """A large short-K 1 x 1 layer with the EfficientNetV2 epilogues: SiLU, and `act(conv + bias) + residual`."""
     from imagescry_amd import _lib
     from imagescry_amd.embedding import _conv
     from imagescry_amd.resnet50 import FoldedConv
