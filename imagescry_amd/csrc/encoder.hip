@@ -76,7 +76,7 @@ __device__ __forceinline__ void conv_dma16(const void* gsrc, unsigned char* lds_
 // staging registers, no LDS store instructions; the fragment reads then have to be inline asm (a C++ LDS load makes hipcc
 // drain the DMA in flight before it).  Used whenever no per-element transform of x is asked for (`sub`, `scale`).
 template <int TCO, int TPIX, bool TAP4, bool DMA>
-__global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
+__global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int ntiles) {
     constexpr int WCO = TCO >= 64 ? TCO / 64 : 1;  // waves along the output channels
     constexpr int MI = TCO / WCO / 16;             // 16-channel blocks per wave: 4, or 2 for the 32-channel tile
     constexpr int NA = TCO * 8 / 256;      // 16-byte staging slots per thread, weight tile
@@ -91,39 +91,54 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
     const int wave = tid >> 6;
     const int wco = wave % WCO;
     const int wpix = wave / WCO;
-    // 1-D grid, output-channel tile fastest: the workgroups that re-read one pixel tile run back to back
+    // Tiles are numbered output-channel tile fastest (the workgroups that re-read one pixel tile run back to back).  The
+    // LDS-DMA instantiations are PERSISTENT: gridDim.x workgroups (two per CU) walk the tiles blockIdx.x, + gridDim.x, ...
     const int n_co_tiles = (p.Cout + TCO - 1) / TCO;
-    const int co0 = (int)(blockIdx.x % n_co_tiles) * TCO;
-    const int pix0 = (int)(blockIdx.x / n_co_tiles) * TPIX;
 
     // ---- staging assignment: slot = tid + 256 * i  ->  row (tid >> 3) + 32 * i, physical chunk tid & 7
     const int srow = tid >> 3;
     const int lchunk = (tid & 7) ^ ((srow >> 1) & 7);  // logical chunk held by this slot ((32 i) >> 1 is 0 mod 8)
 
-    int a_off[NA];  // element offset of the weight row (clamped to the last output channel)
-#pragma unroll
-    for (int i = 0; i < NA; ++i) a_off[i] = min(co0 + srow + 32 * i, p.Cout - 1) * p.K + lchunk * 4;
-
+    int a_off[NA];   // element offset of the weight row (clamped to the last output channel)
     int b_img[NB];   // image index (for the optional per-image input scale)
     int b_base[NB];  // element offset of image b
     int b_hw0[NB];   // (ho * stride - pad) << 16 | (wo * stride - pad) & 0xffff ; rows past M are pushed out of range
+    // packed-K cursor of this lane's chunk (see dma_step): filter tap (pk_r, pk_s), 16-byte piece pk_c4 of its channels
+    int pk_r = 0, pk_s = 0, pk_c4 = 0;
+    // the staging addresses of one tile (the state dma_step / load_step walk through its K steps)
+    auto set_tile = [&](int tile) {
+        const int tco0 = (tile % n_co_tiles) * TCO;
+        const int tpix0 = (tile / n_co_tiles) * TPIX;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int m = pix0 + srow + 32 * i;
-        if (m < p.M) {
-            const int b = m / (p.Ho * p.Wo);
-            const int rem = m - b * p.Ho * p.Wo;
-            const int ho = rem / p.Wo;
-            const int wo = rem - ho * p.Wo;
-            b_img[i] = b;
-            b_base[i] = b * p.H * p.W * p.Cin + (TAP4 ? 0 : lchunk * 4);
-            b_hw0[i] = ((ho * p.stride - p.pad) << 16) | ((wo * p.stride - p.pad) & 0xffff);
-        } else {
-            b_img[i] = 0;
-            b_base[i] = 0;
-            b_hw0[i] = (int)0x80008000;  // hi0 = wi0 = -32768: never inside the image
+        for (int i = 0; i < NA; ++i) a_off[i] = min(tco0 + srow + 32 * i, p.Cout - 1) * p.K + lchunk * 4;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int m = tpix0 + srow + 32 * i;
+            if (m < p.M) {
+                const int b = m / (p.Ho * p.Wo);
+                const int rem = m - b * p.Ho * p.Wo;
+                const int ho = rem / p.Wo;
+                const int wo = rem - ho * p.Wo;
+                b_img[i] = b;
+                b_base[i] = b * p.H * p.W * p.Cin + (TAP4 ? 0 : lchunk * 4);
+                b_hw0[i] = ((ho * p.stride - p.pad) << 16) | ((wo * p.stride - p.pad) & 0xffff);
+            } else {
+                b_img[i] = 0;
+                b_base[i] = 0;
+                b_hw0[i] = (int)0x80008000;  // hi0 = wi0 = -32768: never inside the image
+            }
         }
-    }
+        if constexpr (TAP4 && DMA) {
+            const int tap0 = lchunk / p.cin4;
+            pk_c4 = lchunk - tap0 * p.cin4;
+            pk_r = tap0 / p.S;
+            pk_s = tap0 - pk_r * p.S;
+        }
+    };
+    int tile = blockIdx.x;
+    set_tile(tile);
+    int co0 = (tile % n_co_tiles) * TCO;   // of the tile being COMPUTED (set_tile may already describe the next one)
+    int pix0 = (tile / n_co_tiles) * TPIX;
 
     // ---- fragment read offsets
     const int frow = lane & 15;
@@ -133,9 +148,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) foff[cc] = frow * 128 + (((cc * 4 + fg) ^ fsw) << 4);
 
-    // The accumulators start as bias + residual (issued first, so these loads fly while the first K step is staged):
-    // the epilogue is then only the activation and the store.  16x16 MFMA result layout: column (pixel) = lane & 15,
-    // rows (channels) = 4 * (lane >> 4) + 0..3.
+    // 16x16 MFMA result layout: column (pixel) = lane & 15, rows (channels) = 4 * (lane >> 4) + 0..3.  In the
+    // register-staged instantiations the accumulators start as bias + residual and the epilogue is only the activation and
+    // the store; the LDS-DMA ones start from zero and add both in the epilogue, from loads that fly under the last K step
+    // (as initial values their latency sat in front of the first MFMA of every tile).
     f32x4 acc[MI][4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -144,10 +160,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
         for (int mi = 0; mi < MI; ++mi) {
             const int co = co0 + wco * (MI * 16) + mi * 16 + (lane >> 4) * 4;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (m < p.M && co < p.Cout) {
+            if (!DMA && m < p.M && co < p.Cout) {
                 if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + co);
-                if (!DMA && p.res && !p.res_after_act)
-                    v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
+                if (p.res && !p.res_after_act) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
             }
             acc[mi][ni] = v;
         }
@@ -215,14 +230,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
 
     // LDS-DMA form of load_step + store_step: this thread's slots of K step ks straight into buffer buf.  Wave w's 64
     // lanes cover rows 8 w .. 8 w + 7 of a staging round (lane-linear 1 KiB), round i is 32 rows (4 KiB) further.
-    // packed-K cursor of this lane's chunk (see dma_step): filter tap (pk_r, pk_s), 16-byte piece pk_c4 of its channels
-    int pk_r = 0, pk_s = 0, pk_c4 = 0;
-    if constexpr (TAP4 && DMA) {
-        const int tap0 = lchunk / p.cin4;
-        pk_c4 = lchunk - tap0 * p.cin4;
-        pk_r = tap0 / p.S;
-        pk_s = tap0 - pk_r * p.S;
-    }
     auto dma_step = [&](int ks, int buf) {
         unsigned char* a = lds + buf * BUF_BYTES + (tid >> 6) * 1024;
         unsigned char* b = a + A_BYTES;
@@ -265,10 +272,43 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
         }
     };
 
-    f32x4 rv[MI][4];  // residual tile (LDS-DMA path: loaded during the last K step)
+    f32x4 rv[MI][4];  // residual tile and bias of the LDS-DMA path: loaded during the last K step
+    f32x4 bv[MI];
+    // ---- epilogue: activation and one 16-byte store per (pixel, four channels).  The activation is chosen ONCE, outside
+    // the element loops (looked at per element, the switch is a tenth of a short-K tile's time in scalar branches).
+    auto epilogue = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int m = pix0 + wpix * 64 + ni * 16 + frow;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int co = co0 + wco * (MI * 16) + mi * 16 + fg * 4;
+                if (co >= p.Cout) continue;  // Cout % 4 == 0, so a lane's four channels are in or out together
+                f32x4 v = acc[mi][ni];
+                if (DMA) v += bv[mi];
+                if (DMA && p.res && !p.res_after_act) v += rv[mi][ni];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], ACT < 0 ? p.act : ACT);
+                if (p.res && p.res_after_act) {
+                    if (DMA) v += rv[mi][ni];
+                    else v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
+                }
+                *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.Cout + co) = v;
+            }
+        }
+    };
+    auto run_epilogue = [&]() {
+        if (p.act == ISC_ACT_NONE) epilogue(IntTag<ISC_ACT_NONE>{});
+        else if (p.act == ISC_ACT_RELU) epilogue(IntTag<ISC_ACT_RELU>{});
+        else if (p.act == ISC_ACT_SILU) epilogue(IntTag<ISC_ACT_SILU>{});
+        else epilogue(IntTag<-1>{});
+    };
+
     if constexpr (DMA) {
         dma_step(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // also the bias / residual loads of the accumulators
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
         // one K step of matrix work out of buffer buf (fragment reads in asm, see above)
@@ -328,35 +368,72 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
-        // The residual tile is fetched under the LAST K step and added in the epilogue.  (As part of the accumulators'
-        // initial value its latency sat in front of the first MFMA of every tile: measured on 14 x 14 x 256 -> 1024,
-        // B = 512: 676 us with the residual, 546 without -- the whole read, un-overlapped; now 632.  Fetching it one
-        // step earlier still needs more registers than there are: 160-200 bytes of scratch and a slower network.)
-        auto fetch_residual = [&]() {
-            if (!p.res) return;
-            // 32-bit element offsets from the uniform base (M * Cout < 2^31, checked by the host): one VGPR per pixel row,
-            // the channel blocks are immediate offsets
+        // Bias and residual tile of the tile being computed: fetched under its LAST K step, added in the epilogue.  (As
+        // part of the accumulators' initial value the residual's latency sat in front of the first MFMA of every tile:
+        // measured on 14 x 14 x 256 -> 1024, B = 512: 676 us with the residual, 546 without -- the whole read,
+        // un-overlapped.  Fetching it one step earlier needs more registers than there are: 160-200 bytes of scratch
+        // and a slower network.)
+        auto fetch_bias_residual = [&]() {
             const int cob = co0 + wco * (MI * 16) + (lane >> 4) * 4;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)  // channel blocks past Cout read the last whole block: never stored
+                bv[mi] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + min(cob + mi * 16, p.Cout - 4))
+                                : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!p.res) return;
+            // 32-bit element offsets from the uniform base (M * Cout < 2^31, checked by the host)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const int m = pix0 + wpix * 64 + ni * 16 + (lane & 15);
-                const unsigned off = (unsigned)min(m, p.M - 1) * (unsigned)p.Cout + (unsigned)cob;
+                const unsigned row = (unsigned)min(m, p.M - 1) * (unsigned)p.Cout;  // rows past M read row M - 1
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    // rows past M read row M - 1, channel blocks past Cout read the last whole block: never stored
-                    const unsigned o = cob + mi * 16 < p.Cout ? off + mi * 16 : (unsigned)min(m, p.M - 1) * (unsigned)p.Cout + (unsigned)(p.Cout - 4);
-                    rv[mi][ni] = *reinterpret_cast<const f32x4*>(p.res + o);
-                }
+                for (int mi = 0; mi < MI; ++mi)
+                    rv[mi][ni] = *reinterpret_cast<const f32x4*>(p.res + (row + (unsigned)min(cob + mi * 16, p.Cout - 4)));
             }
         };
-        for (int ks = 0; ks + 1 < p.ksteps; ++ks) {
-            const int buf = ks & 1;
-            dma_step(ks + 1, buf ^ 1);
-            k_step(buf);
-            step_end();
+        int base = 0;  // buffer parity of this tile's K step 0
+        for (;;) {
+            for (int ks = 0; ks + 1 < p.ksteps; ++ks) {
+                const int buf = (ks + base) & 1;
+                dma_step(ks + 1, buf ^ 1);
+                k_step(buf);
+                step_end();
+            }
+            // last K step of this tile: the other buffer is free (the barrier of the step before says so), so the NEXT
+            // tile's K step 0 is staged into it now and no tile after the first starts with an exposed DMA latency
+            const int last = (p.ksteps - 1 + base) & 1;
+            const int next = tile + (int)gridDim.x;
+            if (next < ntiles) {
+                set_tile(next);
+                dma_step(0, last ^ 1);
+            }
+            fetch_bias_residual();
+            k_step(last);
+            // bias, residual and the next tile's first step have landed (this wave's share); nothing younger is in
+            // flight, so the stores below drain under the next tile's first K step instead of being waited for here.
+            // (The empty asm pins bias and residual HERE: left to itself hipcc re-waits -- vmcnt(0), i.e. for the store
+            // just issued -- inside every conditional block of the epilogue.)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                asm volatile("" : "+v"(bv[mi]));
+                if (p.res) asm volatile("" : "+v"(rv[mi][0]), "+v"(rv[mi][1]), "+v"(rv[mi][2]), "+v"(rv[mi][3]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            run_epilogue();
+            if (next >= ntiles) break;
+            __builtin_amdgcn_s_barrier();  // every wave's share has landed; every wave is done with buffer `last`
+            __builtin_amdgcn_sched_barrier(0);
+            base = last ^ 1;
+            tile = next;
+            co0 = (tile % n_co_tiles) * TCO;
+            pix0 = (tile / n_co_tiles) * TPIX;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        fetch_residual();
-        k_step((p.ksteps - 1) & 1);
+        return;
     } else {
     load_step(0);
     store_step(0);
@@ -390,35 +467,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p) {
         __syncthreads();
     }
     }
-
-    // ---- epilogue: activation and one 16-byte store per (pixel, four channels).  The activation is chosen ONCE, outside
-    // the element loops (looked at per element, the switch is a tenth of a short-K tile's time in scalar branches).
-    auto epilogue = [&](auto act_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int m = pix0 + wpix * 64 + ni * 16 + frow;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int co = co0 + wco * (MI * 16) + mi * 16 + fg * 4;
-                if (co >= p.Cout) continue;  // Cout % 4 == 0, so a lane's four channels are in or out together
-                f32x4 v = acc[mi][ni];
-                if (DMA && p.res && !p.res_after_act) v += rv[mi][ni];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], ACT < 0 ? p.act : ACT);
-                if (p.res && p.res_after_act) {
-                    if (DMA) v += rv[mi][ni];
-                    else v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
-                }
-                *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.Cout + co) = v;
-            }
-        }
-    };
-    if (p.act == ISC_ACT_NONE) epilogue(IntTag<ISC_ACT_NONE>{});
-    else if (p.act == ISC_ACT_RELU) epilogue(IntTag<ISC_ACT_RELU>{});
-    else if (p.act == ISC_ACT_SILU) epilogue(IntTag<ISC_ACT_SILU>{});
-    else epilogue(IntTag<-1>{});
+    run_epilogue();
 }
 
 __global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ x, int C, int HW, int Cpad, size_t total,
@@ -769,6 +818,25 @@ static bool conv_no_dma() {
 static constexpr bool conv_no_dma() { return false; }
 #endif
 
+static int conv_cu_count() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return cus;
+    }();
+    return n;
+}
+#ifdef ISC_ABLATION
+static bool conv_one_tile_per_wg() {
+    static const bool v = getenv("ISC_CONV_NO_PERSIST") != nullptr;  // A/B aid: one workgroup per tile, as before
+    return v;
+}
+#else
+static constexpr bool conv_one_tile_per_wg() { return false; }
+#endif
+
 static int conv_launch(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S, int stride,
                        int pad, const float* bias, const float* residual, const float* sub, const float* scale, int act,
                        float* out, void* stream) {
@@ -800,31 +868,30 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     // 64-channel tiles wherever they pad Cout less than 128-channel ones do (Cout <= 64, but also 160 -> 192 instead of
     // 256, 192 -> 192 instead of 256): the wasted quarter of the matrix work is worth more than the extra tile reloads
     const bool narrow = isc_ceil_div(Cout, 64) * 64 < isc_ceil_div(Cout, 128) * 128;
-    if (Cout <= 32 && !sub && !scale && !conv_no_dma()) {  // half the matrix work of the 64-channel tile
-        const int64_t nb = isc_ceil_div<int64_t>(M, 256);
-        if (nb > 0x7fffffff) return ISC_ERR_UNSUPPORTED;
-        isc_timing_begin(ISC_KERNEL_CONV, s);
-        if (tap4) hipLaunchKernelGGL((k_conv_f32<32, 256, true, true>), dim3((unsigned)nb), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((k_conv_f32<32, 256, false, true>), dim3((unsigned)nb), dim3(256), 0, s, p);
-        isc_timing_end(ISC_KERNEL_CONV, s);
-        return isc_launch_status();
-    }
-    const int64_t blocks = narrow ? isc_ceil_div(Cout, 64) * isc_ceil_div<int64_t>(M, 256)
-                                  : isc_ceil_div(Cout, 128) * isc_ceil_div<int64_t>(M, 128);
-    if (blocks > 0x7fffffff) return ISC_ERR_UNSUPPORTED;
-    isc_timing_begin(ISC_KERNEL_CONV, s);
-    const dim3 grid((unsigned)blocks), block(256);
     const bool dma = !sub && !scale && !conv_no_dma();
-    if (dma) {
-        if (narrow && tap4) hipLaunchKernelGGL((k_conv_f32<64, 256, true, true>), grid, block, 0, s, p);
-        else if (narrow) hipLaunchKernelGGL((k_conv_f32<64, 256, false, true>), grid, block, 0, s, p);
-        else if (tap4) hipLaunchKernelGGL((k_conv_f32<128, 128, true, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((k_conv_f32<128, 128, false, true>), grid, block, 0, s, p);
+    const bool tile32 = Cout <= 32 && dma;  // half the matrix work of the 64-channel tile
+    const int64_t blocks = tile32   ? isc_ceil_div<int64_t>(M, 256)
+                           : narrow ? isc_ceil_div(Cout, 64) * isc_ceil_div<int64_t>(M, 256)
+                                    : isc_ceil_div(Cout, 128) * isc_ceil_div<int64_t>(M, 128);
+    if (blocks > 0x7fffffff) return ISC_ERR_UNSUPPORTED;
+    const int ntiles = (int)blocks;
+    // the LDS-DMA kernels are persistent: two workgroups per CU (what their LDS and registers allow) walk the tiles
+    const int64_t resident = 2 * (int64_t)conv_cu_count();
+    const dim3 grid((unsigned)(dma && !conv_one_tile_per_wg() && blocks > resident ? resident : blocks)), block(256);
+    isc_timing_begin(ISC_KERNEL_CONV, s);
+    if (tile32) {
+        if (tap4) hipLaunchKernelGGL((k_conv_f32<32, 256, true, true>), grid, block, 0, s, p, ntiles);
+        else hipLaunchKernelGGL((k_conv_f32<32, 256, false, true>), grid, block, 0, s, p, ntiles);
+    } else if (dma) {
+        if (narrow && tap4) hipLaunchKernelGGL((k_conv_f32<64, 256, true, true>), grid, block, 0, s, p, ntiles);
+        else if (narrow) hipLaunchKernelGGL((k_conv_f32<64, 256, false, true>), grid, block, 0, s, p, ntiles);
+        else if (tap4) hipLaunchKernelGGL((k_conv_f32<128, 128, true, true>), grid, block, 0, s, p, ntiles);
+        else hipLaunchKernelGGL((k_conv_f32<128, 128, false, true>), grid, block, 0, s, p, ntiles);
     } else {
-        if (narrow && tap4) hipLaunchKernelGGL((k_conv_f32<64, 256, true, false>), grid, block, 0, s, p);
-        else if (narrow) hipLaunchKernelGGL((k_conv_f32<64, 256, false, false>), grid, block, 0, s, p);
-        else if (tap4) hipLaunchKernelGGL((k_conv_f32<128, 128, true, false>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((k_conv_f32<128, 128, false, false>), grid, block, 0, s, p);
+        if (narrow && tap4) hipLaunchKernelGGL((k_conv_f32<64, 256, true, false>), grid, block, 0, s, p, ntiles);
+        else if (narrow) hipLaunchKernelGGL((k_conv_f32<64, 256, false, false>), grid, block, 0, s, p, ntiles);
+        else if (tap4) hipLaunchKernelGGL((k_conv_f32<128, 128, true, false>), grid, block, 0, s, p, ntiles);
+        else hipLaunchKernelGGL((k_conv_f32<128, 128, false, false>), grid, block, 0, s, p, ntiles);
     }
     isc_timing_end(ISC_KERNEL_CONV, s);
     return isc_launch_status();

@@ -45,6 +45,12 @@ def _rel_err(got: torch.Tensor, exp: torch.Tensor) -> float:
         (8, 130, 130, 64, 256, 1, 1, 0),  # ResNet layer1 expand: two K steps per tile
         (4, 129, 129, 256, 512, 1, 1, 0),
         (2, 200, 200, 32, 1024, 1, 1, 0),  # ONE K step per tile
+        # more tiles than resident workgroups (two per CU): every workgroup walks several tiles, staging the next
+        # tile's first K step under the last one of the current tile -- odd and even K-step counts, all three tile shapes
+        (8, 150, 150, 32, 64, 1, 1, 0),  # 64 x 256 tiles, one K step
+        (8, 150, 150, 96, 64, 1, 1, 0),  # ... three
+        (8, 150, 150, 64, 24, 1, 1, 0),  # 32 x 256 tiles, two K steps
+        (6, 75, 75, 32, 128, 3, 1, 1),  # 128 x 128 tiles, nine K steps, padding taps
     ],
 )
 @pytest.mark.parametrize("epilogue", ["plain", "bias_relu", "bias_res_relu"])
@@ -138,6 +144,8 @@ def test_conv2d_stem_mode(b, h, w, cout, k, stride, pad, device: torch.device) -
         (2, 9, 9, 80, 160, 1, 1, 0),  # EfficientNetV2-M: 80 = 2.5 K steps
         (2, 9, 9, 8, 132, 5, 2, 2),  # 2 chunks per tap, Cout over one 128 tile
         (4, 1, 1, 40, 960, 1, 1, 0),  # squeeze-excitation fc2 from an unpadded squeeze width
+        (8, 150, 150, 24, 24, 3, 1, 1),  # packed-K over more tiles than resident workgroups (32 x 256 tiles)
+        (8, 150, 150, 8, 48, 3, 2, 1),  # ... 64 x 256 tiles would need Cout > 32: 48 -> 64 x 256, stride 2
     ],
 )
 @pytest.mark.parametrize("epilogue", ["bias_silu", "bias_silu_then_res"])
