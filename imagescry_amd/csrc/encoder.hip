@@ -39,6 +39,8 @@ struct ConvParams {
     int ksteps;     // R * S * cin_steps
     int act;
     int res_after_act;  // out = act(conv + bias) + residual instead of act(conv + bias + residual)
+    int tile_base;      // this launch's tile 0 in the layer's full-tile numbering
+    int tile_split;     // 1, or 2 when the launch computes half tiles (pixel halves) of the full tiles
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
     constexpr int MI = TCO / WCO / 16;             // 16-channel blocks per wave: 4, or 2 for the 32-channel tile
     constexpr int NA = TCO * 8 / 256;      // 16-byte staging slots per thread, weight tile
     constexpr int NB = TPIX * 8 / 256;     // ... pixel tile
+    constexpr int NI = TPIX / (4 / WCO) / 16;      // 16-pixel blocks per wave: 4, or 2 for the 64-pixel half tile
     constexpr int A_BYTES = TCO * 128;
     constexpr int B_BYTES = TPIX * 128;
     constexpr int BUF_BYTES = A_BYTES + B_BYTES;
@@ -106,9 +109,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
     // packed-K cursor of this lane's chunk (see dma_step): filter tap (pk_r, pk_s), 16-byte piece pk_c4 of its channels
     int pk_r = 0, pk_s = 0, pk_c4 = 0;
     // the staging addresses of one tile (the state dma_step / load_step walk through its K steps)
+    // Tile t of this launch is tile p.tile_base + t / p.tile_split of the layer's FULL-tile numbering (pixel tiles of
+    // TPIX * p.tile_split), and piece t % p.tile_split of its pixels: the remainder round of a layer is launched as
+    // half tiles (conv_launch).
+    auto tile_origin = [&](int t, int& oc, int& op) {
+        const int full = p.tile_base + t / p.tile_split;
+        oc = (full % n_co_tiles) * TCO;
+        op = (full / n_co_tiles) * (TPIX * p.tile_split) + (t % p.tile_split) * TPIX;
+    };
     auto set_tile = [&](int tile) {
-        const int tco0 = (tile % n_co_tiles) * TCO;
-        const int tpix0 = (tile / n_co_tiles) * TPIX;
+        int tco0, tpix0;
+        tile_origin(tile, tco0, tpix0);
 #pragma unroll
         for (int i = 0; i < NA; ++i) a_off[i] = min(tco0 + srow + 32 * i, p.Cout - 1) * p.K + lchunk * 4;
 #pragma unroll
@@ -137,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
     };
     int tile = blockIdx.x;
     set_tile(tile);
-    int co0 = (tile % n_co_tiles) * TCO;   // of the tile being COMPUTED (set_tile may already describe the next one)
-    int pix0 = (tile / n_co_tiles) * TPIX;
+    int co0, pix0;  // of the tile being COMPUTED (set_tile may already describe the next one)
+    tile_origin(tile, co0, pix0);
 
     // ---- fragment read offsets
     const int frow = lane & 15;
@@ -152,10 +163,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
     // register-staged instantiations the accumulators start as bias + residual and the epilogue is only the activation and
     // the store; the LDS-DMA ones start from zero and add both in the epilogue, from loads that fly under the last K step
     // (as initial values their latency sat in front of the first MFMA of every tile).
-    f32x4 acc[MI][4];
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int m = pix0 + wpix * 64 + ni * 16 + (lane & 15);
+    for (int ni = 0; ni < NI; ++ni) {
+        const int m = pix0 + wpix * (NI * 16) + ni * 16 + (lane & 15);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int co = co0 + wco * (MI * 16) + mi * 16 + (lane >> 4) * 4;
@@ -272,15 +283,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
         }
     };
 
-    f32x4 rv[MI][4];  // residual tile and bias of the LDS-DMA path: loaded during the last K step
+    f32x4 rv[MI][NI];  // residual tile and bias of the LDS-DMA path: loaded during the last K step
     f32x4 bv[MI];
     // ---- epilogue: activation and one 16-byte store per (pixel, four channels).  The activation is chosen ONCE, outside
     // the element loops (looked at per element, the switch is a tenth of a short-K tile's time in scalar branches).
     auto epilogue = [&](auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int m = pix0 + wpix * 64 + ni * 16 + frow;
+        for (int ni = 0; ni < NI; ++ni) {
+            const int m = pix0 + wpix * (NI * 16) + ni * 16 + frow;
             if (m >= p.M) continue;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
@@ -314,8 +325,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
         // one K step of matrix work out of buffer buf (fragment reads in asm, see above)
         auto k_step = [&](int buf) {
             const unsigned a_img = lds_addr + buf * BUF_BYTES + wco * (MI * 16) * 128;
-            const unsigned b_img = lds_addr + buf * BUF_BYTES + A_BYTES + wpix * 64 * 128;
-            u32x4 a[2][MI], b[2][4];
+            const unsigned b_img = lds_addr + buf * BUF_BYTES + A_BYTES + wpix * (NI * 16) * 128;
+            u32x4 a[2][MI], b[2][NI];
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 CONV_DS_READ(a[cc][0], a_img + foff[cc], 0);
@@ -326,10 +337,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
                 }
                 CONV_DS_READ(b[cc][0], b_img + foff[cc], 0);
                 CONV_DS_READ(b[cc][1], b_img + foff[cc], 2048);
-                CONV_DS_READ(b[cc][2], b_img + foff[cc], 4096);
-                CONV_DS_READ(b[cc][3], b_img + foff[cc], 6144);
+                if constexpr (NI == 4) {
+                    CONV_DS_READ(b[cc][2], b_img + foff[cc], 4096);
+                    CONV_DS_READ(b[cc][3], b_img + foff[cc], 6144);
+                }
             }
-            if constexpr (MI == 4)
+            static_assert((MI == 4 && NI == 4) || (MI == 2 && NI == 4) || (MI == 4 && NI == 2), "wave tile");
+            if constexpr (NI == 2)
+                asm volatile("s_waitcnt lgkmcnt(6)"
+                             : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]), "+v"(b[0][1]));
+            else if constexpr (MI == 4)
                 asm volatile("s_waitcnt lgkmcnt(8)"
                              : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]), "+v"(b[0][1]),
                                "+v"(b[0][2]), "+v"(b[0][3]));
@@ -342,10 +359,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
+                    for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[0][mi][j]),
                                                                            __uint_as_float(b[0][ni][j]), acc[mi][ni], 0, 0, 0);
-            if constexpr (MI == 4)
+            if constexpr (NI == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[1][0]), "+v"(b[1][1]));
+            else if constexpr (MI == 4)
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[1][0]), "+v"(b[1][1]),
                                "+v"(b[1][2]), "+v"(b[1][3]));
@@ -358,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
+                    for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[1][mi][j]),
                                                                            __uint_as_float(b[1][ni][j]), acc[mi][ni], 0, 0, 0);
         };
@@ -382,8 +402,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
             if (!p.res) return;
             // 32-bit element offsets from the uniform base (M * Cout < 2^31, checked by the host)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int m = pix0 + wpix * 64 + ni * 16 + (lane & 15);
+            for (int ni = 0; ni < NI; ++ni) {
+                const int m = pix0 + wpix * (NI * 16) + ni * 16 + (lane & 15);
                 const unsigned row = (unsigned)min(m, p.M - 1) * (unsigned)p.Cout;  // rows past M read row M - 1
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
@@ -417,7 +437,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 asm volatile("" : "+v"(bv[mi]));
-                if (p.res) asm volatile("" : "+v"(rv[mi][0]), "+v"(rv[mi][1]), "+v"(rv[mi][2]), "+v"(rv[mi][3]));
+                if (p.res) {
+                    asm volatile("" : "+v"(rv[mi][0]), "+v"(rv[mi][1]));
+                    if constexpr (NI == 4) asm volatile("" : "+v"(rv[mi][2]), "+v"(rv[mi][3]));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             run_epilogue();
@@ -426,12 +449,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
             __builtin_amdgcn_sched_barrier(0);
             base = last ^ 1;
             tile = next;
-            co0 = (tile % n_co_tiles) * TCO;
-            pix0 = (tile / n_co_tiles) * TPIX;
-#pragma unroll
+            tile_origin(tile, co0, pix0);
             for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         return;
     } else {
@@ -445,21 +465,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
         if (more) load_step(ks + 1);
 
         const unsigned char* a_img = lds + buf * BUF_BYTES + wco * (MI * 16) * 128;
-        const unsigned char* b_img = lds + buf * BUF_BYTES + A_BYTES + wpix * 64 * 128;
+        const unsigned char* b_img = lds + buf * BUF_BYTES + A_BYTES + wpix * (NI * 16) * 128;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-            u32x4 a[MI], b[4];
+            u32x4 a[MI], b[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const u32x4*>(a_img + mi * 2048 + foff[cc]);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) b[ni] = *reinterpret_cast<const u32x4*>(b_img + ni * 2048 + foff[cc]);
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const u32x4*>(b_img + ni * 2048 + foff[cc]);
             // element j of every lane's chunk feeds the j-th MFMA: a K-axis permutation shared by both operands
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
+                    for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[mi][j]),
                                                                            __uint_as_float(b[ni][j]), acc[mi][ni], 0, 0, 0);
         }
@@ -837,6 +857,15 @@ static bool conv_one_tile_per_wg() {
 static constexpr bool conv_one_tile_per_wg() { return false; }
 #endif
 
+#ifdef ISC_ABLATION
+static bool conv_no_split() {
+    static const bool v = getenv("ISC_CONV_NO_SPLIT") != nullptr;  // A/B aid: no half-tile remainder launch
+    return v;
+}
+#else
+static constexpr bool conv_no_split() { return false; }
+#endif
+
 static int conv_launch(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S, int stride,
                        int pad, const float* bias, const float* residual, const float* sub, const float* scale, int act,
                        float* out, void* stream) {
@@ -863,7 +892,7 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.res = residual; p.sub = sub; p.scale = scale; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
-    p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = tap4 ? 1 : Cin / 32; p.cin4 = Cin / 4; p.ksteps = ksteps; p.act = act; p.res_after_act = res_after_act;
+    p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = tap4 ? 1 : Cin / 32; p.cin4 = Cin / 4; p.ksteps = ksteps; p.act = act; p.res_after_act = res_after_act; p.tile_base = 0; p.tile_split = 1;
     hipStream_t s = isc_stream(stream);
     // 64-channel tiles wherever they pad Cout less than 128-channel ones do (Cout <= 64, but also 160 -> 192 instead of
     // 256, 192 -> 192 instead of 256): the wasted quarter of the matrix work is worth more than the extra tile reloads
@@ -879,6 +908,34 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     const int64_t resident = 2 * (int64_t)conv_cu_count();
     const dim3 grid((unsigned)(dma && !conv_one_tile_per_wg() && blocks > resident ? resident : blocks)), block(256);
     isc_timing_begin(ISC_KERNEL_CONV, s);
+    // A tile count that leaves a thin last round on the resident workgroups (ResNet-50 layer3 / layer4: 1 568 and 784
+    // tiles on 512): whole rounds as one perfectly balanced launch, the remainder as HALF tiles (128 x 64, 64 x 128) in a
+    // second one -- its round then costs half a tile time, or spreads over twice the CUs, instead of a whole one.  Worth a
+    // second launch only when a tile is long (>= 16 K steps) or there is no whole round at all.
+    if (dma && !tile32 && !conv_one_tile_per_wg() && !conv_no_split()) {
+        const int64_t rounds = blocks / resident, rem = blocks - rounds * resident;
+        if (rem > 0 && rem * 4 <= resident * 3 && (ksteps >= 16 || rounds == 0)) {
+            if (rounds > 0) {
+                const dim3 g1((unsigned)resident);
+                const int n1 = (int)(rounds * resident);
+                if (narrow && tap4) hipLaunchKernelGGL((k_conv_f32<64, 256, true, true>), g1, block, 0, s, p, n1);
+                else if (narrow) hipLaunchKernelGGL((k_conv_f32<64, 256, false, true>), g1, block, 0, s, p, n1);
+                else if (tap4) hipLaunchKernelGGL((k_conv_f32<128, 128, true, true>), g1, block, 0, s, p, n1);
+                else hipLaunchKernelGGL((k_conv_f32<128, 128, false, true>), g1, block, 0, s, p, n1);
+            }
+            ConvParams q = p;
+            q.tile_base = (int)(rounds * resident);
+            q.tile_split = 2;
+            const int halves = (int)(2 * rem);
+            const dim3 g2((unsigned)(halves > 3 * resident / 2 ? 3 * resident / 2 : halves));
+            if (narrow && tap4) hipLaunchKernelGGL((k_conv_f32<64, 128, true, true>), g2, block, 0, s, q, halves);
+            else if (narrow) hipLaunchKernelGGL((k_conv_f32<64, 128, false, true>), g2, block, 0, s, q, halves);
+            else if (tap4) hipLaunchKernelGGL((k_conv_f32<128, 64, true, true>), g2, block, 0, s, q, halves);
+            else hipLaunchKernelGGL((k_conv_f32<128, 64, false, true>), g2, block, 0, s, q, halves);
+            isc_timing_end(ISC_KERNEL_CONV, s);
+            return isc_launch_status();
+        }
+    }
     if (tile32) {
         if (tap4) hipLaunchKernelGGL((k_conv_f32<32, 256, true, true>), grid, block, 0, s, p, ntiles);
         else hipLaunchKernelGGL((k_conv_f32<32, 256, false, true>), grid, block, 0, s, p, ntiles);

@@ -51,6 +51,10 @@ def _rel_err(got: torch.Tensor, exp: torch.Tensor) -> float:
         (8, 150, 150, 96, 64, 1, 1, 0),  # ... three
         (8, 150, 150, 64, 24, 1, 1, 0),  # 32 x 256 tiles, two K steps
         (6, 75, 75, 32, 128, 3, 1, 1),  # 128 x 128 tiles, nine K steps, padding taps
+        # long tiles (>= 16 K steps) with a thin last round: whole rounds in one launch, the remainder as half tiles
+        (5, 120, 120, 64, 128, 3, 1, 1),  # 563 tiles of 128 x 128 on 512 resident workgroups: 512 + 51 -> 102 halves
+        (5, 170, 170, 64, 64, 3, 1, 1),  # 565 tiles of 64 x 256: 512 + 53 -> 106 halves of 64 x 128, ragged last half
+        (1, 33, 35, 512, 192, 1, 1, 0),  # no whole round: 15 tiles of 64 x 256 as 30 half tiles (the last one empty)
     ],
 )
 @pytest.mark.parametrize("epilogue", ["plain", "bias_relu", "bias_res_relu"])
