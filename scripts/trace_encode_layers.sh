@@ -8,6 +8,20 @@ rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_enc -- python3 s
 fi
 python3 - <<'PY'
 import csv, glob
+
+def conv_launches(m, kk, cout, resident=512):
+    """How many k_conv_f32 launches isc_conv2d_nhwc makes for a layer (encoder.hip conv_launch): 2 when whole rounds
+    and a half-tile remainder are launched separately."""
+    cdiv = lambda a, b: -(-a // b)
+    ksteps = cdiv(kk, 32)
+    if cout <= 32:
+        return 1
+    narrow = cdiv(cout, 64) * 64 < cdiv(cout, 128) * 128
+    blocks = cdiv(cout, 64) * cdiv(m, 256) if narrow else cdiv(cout, 128) * cdiv(m, 128)
+    rounds, rem = divmod(blocks, resident)
+    if rem > 0 and rem * 4 <= resident * 3 and (ksteps >= 16 or rounds == 0):
+        return 2 if rounds > 0 else 1
+    return 1
 B = 512
 layers = []  # (name, pixels_out, cin*k*k, cout, in_bytes, out_bytes, res_bytes)
 def out(n, k, s, p): return (n + 2 * p - k) // s + 1
@@ -31,13 +45,22 @@ layers.append(("fc 2048->768", B, 2048, 768, B * 2048 * 4, B * 768 * 4, 0))
 import os
 f = max(glob.glob("gpurun_out/prof_enc/*/*kernel_trace.csv"), key=os.path.getmtime)
 rows = [r for r in csv.DictReader(open(f)) if "k_conv_f32" in r["Kernel_Name"] or "k_conv1x1_f32_stream" in r["Kernel_Name"]]
-n = len(layers)
-last = rows[-n:]
+need = [conv_launches(m, k, nn) for (name, m, k, nn, ib, ob, rb) in layers]
+last = rows[-sum(need):]
+merged, pos = [], 0
+for cnt in need:
+    grp = last[pos:pos + cnt]; pos += cnt
+    r0 = dict(grp[0])
+    r0["dur"] = sum(int(g["End_Timestamp"]) - int(g["Start_Timestamp"]) for g in grp)
+    if cnt > 1:
+        r0["Kernel_Name"] = grp[0]["Kernel_Name"].replace(">(", "> + halves(", 1)
+    merged.append(r0)
+last = merged
 tot_t = tot_f = 0
 print(f"{'layer':22s} {'M':>9s} {'K':>5s} {'N':>5s} {'us':>8s} {'TFLOP/s':>8s} {'of peak':>7s} {'GB/s':>7s}  tile")
 agg = {}
 for (name, m, k, nn, ib, ob, rb), r in zip(layers, last):
-    us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    us = r["dur"] / 1e3
     fl = 2.0 * m * k * nn
     tot_t += us; tot_f += fl
     kn = r["Kernel_Name"]
