@@ -59,6 +59,11 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
         [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p,
          c_void_p],
     ),
+    "isc_normalize_clip_nhwc4": (
+        c_int,
+        [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p,
+         c_void_p],
+    ),
     "isc_resize_bilinear": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isc_l2norm_channels": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "isc_bank_packed_bytes": (c_int, [c_int, c_int64, c_int, POINTER(c_size_t)]),

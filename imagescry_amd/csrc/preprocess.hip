@@ -203,6 +203,51 @@ __global__ __launch_bounds__(256) void k_normalize_scalar(const T* __restrict__ 
     }
 }
 
+// The same normalisation written channels-last for the convolution stems: y[b][hw][0..C) = norm_clip(x[b][c][hw]),
+// channels C..3 zero.  PX consecutive pixels per thread (PX = 4 needs HW % 4 == 0): one PX-wide load per plane,
+// PX 16-byte stores (a wave writes 64 * PX * 16 contiguous bytes).
+template <typename T, int PX>
+__global__ __launch_bounds__(256) void k_normalize_nhwc4(const T* __restrict__ x, size_t ngroups, int C, int HW,
+                                                         const float* __restrict__ mean, const float* __restrict__ stdev,
+                                                         int per_image, float eps, float lo, float hi,
+                                                         float* __restrict__ y) {
+    const size_t groups_per_image = (size_t)HW / PX;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = g / groups_per_image;
+        const size_t hw = (g - b * groups_per_image) * PX;
+        float o[PX][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < C) {
+                const int st = per_image ? (int)(b * C + c) : c;
+                const float mu = mean[st];
+                const float denom = stdev[st] + eps;
+                const T* src = x + (b * C + c) * (size_t)HW + hw;
+                T v[PX];
+                if constexpr (PX == 4 && sizeof(T) == 1) {
+                    const unsigned w = *reinterpret_cast<const unsigned*>(src);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (T)((w >> (8 * j)) & 0xffu);
+                } else if constexpr (PX == 4) {
+                    const float4 w = *reinterpret_cast<const float4*>(src);
+                    v[0] = (T)w.x; v[1] = (T)w.y; v[2] = (T)w.z; v[3] = (T)w.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) v[j] = src[j];
+                }
+#pragma unroll
+                for (int j = 0; j < PX; ++j) o[j][c] = norm_clip((float)v[j], mu, denom, lo, hi);
+            } else {
+#pragma unroll
+                for (int j = 0; j < PX; ++j) o[j][c] = 0.f;
+            }
+        }
+        float4* dst = reinterpret_cast<float4*>(y + (b * (size_t)HW + hw) * 4);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) dst[j] = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+    }
+}
+
 // torch upsample_bilinear2d (align_corners=False): src = scale * (dst + 0.5) - 0.5, clamped at 0;
 // i0 = min(int(src), in - 1); i1 = min(i0 + 1, in - 1); l1 = clamp(src - i0, 0, 1); l0 = 1 - l1.
 __device__ __forceinline__ void bilinear_tap(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
@@ -357,6 +402,33 @@ extern "C" int isc_normalize_clip(const void* x, int dtype, int B, int C, int H,
             hipLaunchKernelGGL(k_normalize_scalar<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, p, n, C, HW, mean,
                                stdev, per_image, eps, lo, hi, y);
         }
+    }
+    return isc_launch_status();
+}
+
+extern "C" int isc_normalize_clip_nhwc4(const void* x, int dtype, int B, int C, int H, int W, const float* mean,
+                                        const float* stdev, int stat_batch, float eps, float lo, float hi, float* y,
+                                        void* stream) {
+    ISC_REQUIRE(x && mean && stdev && y && B > 0 && C > 0 && C <= 4 && H > 0 && W > 0);
+    ISC_REQUIRE(dtype == ISC_U8 || dtype == ISC_F32);
+    ISC_REQUIRE(stat_batch == 1 || stat_batch == B);
+    const size_t hw64 = (size_t)H * W;
+    if (hw64 > 0x7fffffffu) return ISC_ERR_UNSUPPORTED;
+    if (!isc_aligned(y, 16)) return ISC_ERR_ALIGNMENT;
+    const int HW = (int)hw64;
+    const int per_image = (stat_batch == B && B > 1) ? 1 : 0;
+    hipStream_t s = isc_stream(stream);
+    const bool vec = HW % 4 == 0 && isc_aligned(x, 16);
+    const size_t ngroups = (size_t)B * (vec ? HW / 4 : HW);
+    const dim3 grid(grid_for(ngroups, 256)), block(256);
+    if (dtype == ISC_U8) {
+        const uint8_t* p = static_cast<const uint8_t*>(x);
+        if (vec) hipLaunchKernelGGL((k_normalize_nhwc4<uint8_t, 4>), grid, block, 0, s, p, ngroups, C, HW, mean, stdev, per_image, eps, lo, hi, y);
+        else hipLaunchKernelGGL((k_normalize_nhwc4<uint8_t, 1>), grid, block, 0, s, p, ngroups, C, HW, mean, stdev, per_image, eps, lo, hi, y);
+    } else {
+        const float* p = static_cast<const float*>(x);
+        if (vec) hipLaunchKernelGGL((k_normalize_nhwc4<float, 4>), grid, block, 0, s, p, ngroups, C, HW, mean, stdev, per_image, eps, lo, hi, y);
+        else hipLaunchKernelGGL((k_normalize_nhwc4<float, 1>), grid, block, 0, s, p, ngroups, C, HW, mean, stdev, per_image, eps, lo, hi, y);
     }
     return isc_launch_status();
 }

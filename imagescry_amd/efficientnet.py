@@ -359,14 +359,19 @@ def _se_gate(pooled: Tensor, fc1: Conv, fc2: Conv) -> Tensor:
 
 def forward_features(net: FoldedEfficientNet, x: Tensor) -> Tensor:
     """float32 NCHW `[B, 3, H, W]` -> float32 NHWC `[B, ceil(H/32), ceil(W/32), 1280]`."""
-    silu, none = _lib.ISC_ACT_SILU, _lib.ISC_ACT_NONE
     lib = _lib.load()
     b, c, h, w = x.shape
     x4 = torch.empty((b, h, w, 4), dtype=torch.float32, device=x.device)
     _lib.check(lib.isc_nchw_to_nhwc(x.data_ptr(), b, c, h, w, 4, x4.data_ptr(), _lib.stream_handle(x.device)),
                "isc_nchw_to_nhwc")
+    return forward_features_nhwc4(net, x4)
+
+
+def forward_features_nhwc4(net: FoldedEfficientNet, x4: Tensor) -> Tensor:
+    """float32 NHWC `[B, H, W, 4]` (RGB + a zero channel) -> float32 NHWC `[B, ceil(H/32), ceil(W/32), 1280]`."""
+    silu, none = _lib.ISC_ACT_SILU, _lib.ISC_ACT_NONE
+    b = x4.shape[0]
     y = _conv(x4, net.stem, silu)
-    del x4
     for blk in net.blocks:
         s = blk.spec
         skip = y if s.residual else None

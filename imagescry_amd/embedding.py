@@ -94,10 +94,18 @@ class EmbeddingModule(ABC):
         """preprocess -> forward -> L2-normalise each embedding vector (reference: embedding.py:57-76)."""
         if not isinstance(batch, ImageBatch):
             raise TypeError(f"batch must be an ImageBatch, got {type(batch).__name__}")
-        x = self.preprocess(batch.images)
-        x = self.forward(x)
+        if type(self)._forward_nhwc4 is not EmbeddingModule._forward_nhwc4:
+            # preprocess and forward back to back: the normalisation writes the stem's channels-last layout directly
+            # (same values as `forward(preprocess(images))`, one pass less over the batch)
+            x = self._forward_nhwc4(self.preprocess(batch.images, _nhwc4=True))
+        else:
+            x = self.forward(self.preprocess(batch.images))
         x = l2_normalize_channels(x)
         return EmbeddingBatch(indices=batch.indices, embeddings=x)
+
+    def _forward_nhwc4(self, x4: Tensor) -> Tensor:
+        """`forward` from the stem's own input layout `[B, H, W, 4]` (RGB + a zero channel); optional."""
+        raise NotImplementedError
 
     def embed_images(
         self,
@@ -125,6 +133,12 @@ class EmbeddingModule(ABC):
         for batch in dataloader:
             results.append(self.predict_step(batch.to(self.device)))
         return results
+
+
+def lib_nchw_to_nhwc(x: Tensor, x4: Tensor) -> int:
+    """float32 `[B, C, H, W]` -> `[B, H, W, 4]` with the channels past C zero (status code of the C call)."""
+    b, c, h, w = x.shape
+    return _lib.load().isc_nchw_to_nhwc(x.data_ptr(), b, c, h, w, 4, x4.data_ptr(), _lib.stream_handle(x.device))
 
 
 def _conv(x: Tensor, conv: resnet50.FoldedConv, act: int, residual: Tensor | None = None) -> Tensor:
@@ -179,9 +193,9 @@ class ResNet50Embedder(EmbeddingModule):
     def embedding_dim(self) -> int:
         return self._embedding_dim
 
-    def preprocess(self, images: Tensor) -> Tensor:
+    def preprocess(self, images: Tensor, *, _nhwc4: bool = False) -> Tensor:
         """Resize so the long side is at most `max_side_length`, then batch-statistics normalise and clip to
-        [-3, 3] (reference: embedding.py:149-165)."""
+        [-3, 3] (reference: embedding.py:149-165).  `_nhwc4`: see `normalize_per_channel`."""
         if not isinstance(images, Tensor) or images.dtype != torch.uint8:
             raise TypeError("images must be a uint8 tensor")
         if images.ndim != 4:
@@ -189,7 +203,7 @@ class ResNet50Embedder(EmbeddingModule):
         h, w = images.shape[-2:]
         if max(h, w) > self.max_side_length:
             images = resize(images, output_size=self.max_side_length, side_ref="long")
-        return normalize_per_channel(images, min_value=-3, max_value=3)
+        return normalize_per_channel(images, min_value=-3, max_value=3, _nhwc4=_nhwc4)
 
     def forward(self, x: Tensor) -> Tensor:
         if not isinstance(x, Tensor) or x.dtype != torch.float32:
@@ -200,35 +214,44 @@ class ResNet50Embedder(EmbeddingModule):
         if self.device != x.device:
             raise ValueError(f"module is on {self.device} but the input is on {x.device}; call .to() first")
         x = x.contiguous()
-        b, _c, h, w = x.shape
+        b, c, h, w = x.shape
+        # NCHW -> NHWC with a zero fourth channel, the layout of the stem
+        x4 = torch.empty((b, h, w, 4), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib_nchw_to_nhwc(x, x4), "isc_nchw_to_nhwc")
+        return self._forward_nhwc4(x4)
+
+    def _forward_nhwc4(self, x4: Tensor) -> Tensor:
+        _lib.require_device(x4, "x")
+        if self.device != x4.device:
+            raise ValueError(f"module is on {self.device} but the input is on {x4.device}; call .to() first")
+        b, h, w, _ = x4.shape
         ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
         # the kernels index with 32-bit element offsets: bound the images per pass
         per_image = max(ho * wo * 256, 1)
         chunk = max(1, min(b, (2**31 - 1) // per_image))
-        out = torch.empty((b, self._embedding_dim), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        out = torch.empty((b, self._embedding_dim), dtype=torch.float32, device=x4.device)
+        with torch.cuda.device(x4.device):
             for b0 in range(0, b, chunk):
-                out[b0 : b0 + chunk] = self._forward_chunk(x[b0 : b0 + chunk])
+                out[b0 : b0 + chunk] = self._forward_chunk(x4[b0 : b0 + chunk])
         return out[:, :, None, None]
 
-    def _forward_chunk(self, x: Tensor) -> Tensor:
+    def _forward_chunk(self, x4: Tensor) -> Tensor:
         lib = _lib.load()
-        stream = _lib.stream_handle(x.device)
+        stream = _lib.stream_handle(x4.device)
         net = self._net
-        b, c, h, w = x.shape
+        b, h, w, _ = x4.shape
+        dev = x4.device
         ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
-        # stem: NCHW -> NHWC with a zero fourth channel, then the 7x7 / 2 convolution in the kernel's packed-K mode
-        x4 = torch.empty((b, h, w, 4), dtype=torch.float32, device=x.device)
-        _lib.check(lib.isc_nchw_to_nhwc(x.data_ptr(), b, c, h, w, 4, x4.data_ptr(), stream), "isc_nchw_to_nhwc")
-        y = torch.empty((b, ho, wo, 64), dtype=torch.float32, device=x.device)
+        # stem: the 7x7 / 2 convolution in the kernel's packed-K mode (RGB + a zero channel)
+        y = torch.empty((b, ho, wo, 64), dtype=torch.float32, device=dev)
         st = lib.isc_conv2d_nhwc(
             x4.data_ptr(), b, h, w, 4, net.stem.weight.data_ptr(), 64, 7, 7, 2, 3, net.stem.bias.data_ptr(), None,
             _lib.ISC_ACT_RELU, y.data_ptr(), stream,
         )
         _lib.check(st, "isc_conv2d_nhwc (stem)")
-        del x4
         hp, wp = (ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1
-        pooled = torch.empty((b, hp, wp, 64), dtype=torch.float32, device=x.device)
+        pooled = torch.empty((b, hp, wp, 64), dtype=torch.float32, device=dev)
         _lib.check(lib.isc_maxpool_nhwc(y.data_ptr(), b, ho, wo, 64, 3, 2, 1, pooled.data_ptr(), stream),
                    "isc_maxpool_nhwc")
         y = pooled
@@ -238,7 +261,7 @@ class ResNet50Embedder(EmbeddingModule):
             t = _conv(t, blk.conv2, _lib.ISC_ACT_RELU)
             y = _conv(t, blk.conv3, _lib.ISC_ACT_RELU, residual=identity)
         bb, hh, ww, cc = y.shape
-        feat = torch.empty((bb, 1, 1, cc), dtype=torch.float32, device=x.device)
+        feat = torch.empty((bb, 1, 1, cc), dtype=torch.float32, device=dev)
         _lib.check(lib.isc_global_avgpool_nhwc(y.data_ptr(), bb, hh, ww, cc, feat.data_ptr(), stream),
                    "isc_global_avgpool_nhwc")
         return _conv(feat, net.fc, _lib.ISC_ACT_NONE).reshape(bb, self._embedding_dim)
@@ -284,8 +307,8 @@ class EfficientNetEmbedder(EmbeddingModule):
     def embedding_dim(self) -> int:
         return self._embedding_dim
 
-    def preprocess(self, images: Tensor) -> Tensor:
-        """reference: embedding.py:149-165."""
+    def preprocess(self, images: Tensor, *, _nhwc4: bool = False) -> Tensor:
+        """reference: embedding.py:149-165.  `_nhwc4`: see `normalize_per_channel`."""
         if not isinstance(images, Tensor) or images.dtype != torch.uint8:
             raise TypeError("images must be a uint8 tensor")
         if images.ndim != 4:
@@ -293,7 +316,7 @@ class EfficientNetEmbedder(EmbeddingModule):
         h, w = images.shape[-2:]
         if max(h, w) > self.max_side_length:
             images = resize(images, output_size=self.max_side_length, side_ref="long")
-        return normalize_per_channel(images, min_value=-3, max_value=3)
+        return normalize_per_channel(images, min_value=-3, max_value=3, _nhwc4=_nhwc4)
 
     def forward(self, x: Tensor) -> Tensor:
         """float32 `[B, 3, H, W]` -> float32 `[B, 1280, ceil(H/32), ceil(W/32)]` (an NCHW view of the kernels'
@@ -307,13 +330,23 @@ class EfficientNetEmbedder(EmbeddingModule):
             raise ValueError(f"module is on {self.device} but the input is on {x.device}; call .to() first")
         x = x.contiguous()
         b, _c, h, w = x.shape
+        x4 = torch.empty((b, h, w, 4), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib_nchw_to_nhwc(x, x4), "isc_nchw_to_nhwc")
+        return self._forward_nhwc4(x4)
+
+    def _forward_nhwc4(self, x4: Tensor) -> Tensor:
+        _lib.require_device(x4, "x")
+        if self.device != x4.device:
+            raise ValueError(f"module is on {self.device} but the input is on {x4.device}; call .to() first")
+        b, h, w, _ = x4.shape
         ho, wo = (h + 1) // 2, (w + 1) // 2
         per_image = max(ho * wo * 256, 1)  # largest activation of one image, in elements (32-bit kernel offsets)
         chunk = max(1, min(b, (2**31 - 1) // per_image))
         outs = []
-        with torch.cuda.device(x.device):
+        with torch.cuda.device(x4.device):
             for b0 in range(0, b, chunk):
-                outs.append(efficientnet.forward_features(self._net, x[b0 : b0 + chunk]))
+                outs.append(efficientnet.forward_features_nhwc4(self._net, x4[b0 : b0 + chunk]))
         y = outs[0] if len(outs) == 1 else torch.cat(outs)
         return y.permute(0, 3, 1, 2)
 

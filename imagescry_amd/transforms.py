@@ -124,11 +124,15 @@ def normalize_per_channel(
     min_value: float | None = None,
     max_value: float | None = None,
     eps: float = 1e-6,
+    _nhwc4: bool = False,
 ) -> Tensor:
     """`clip((x - mean_c) / (std_c + eps), min_value, max_value)` as float32 (reference: transforms.py:16-74).
 
     Without caller-supplied statistics the mean and the UNBIASED standard deviation are taken per channel over
     the whole batch (dims 0, 2, 3), so the result depends on the batch composition, exactly as in the reference.
+
+    `_nhwc4` (not part of the reference's signature; used by `predict_step`): write the same values channels-last as
+    `[B, H, W, 4]` with the channels past C zero -- the layout the convolution stems read (C <= 4).
     """
     if not isinstance(image_tensor, Tensor):
         raise TypeError(f"image_tensor must be a torch.Tensor, got {type(image_tensor).__name__}")
@@ -136,7 +140,9 @@ def normalize_per_channel(
         raise ValueError(f"image_tensor must have shape [B, C, H, W], got {tuple(image_tensor.shape)}")
     x = _kernel_input(image_tensor, "image_tensor")
     b, c, h, w = x.shape
-    y = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device)
+    if _nhwc4 and c > 4:
+        raise ValueError(f"the channels-last output holds at most 4 channels, got {c}")
+    y = torch.empty((b, h, w, 4) if _nhwc4 else (b, c, h, w), dtype=torch.float32, device=x.device)
     if x.numel() == 0:
         return y
     mean = std = None
@@ -159,7 +165,7 @@ def normalize_per_channel(
     hi = math.inf if max_value is None else float(max_value)
     lib = _lib.load()
     with torch.cuda.device(x.device):
-        st = lib.isc_normalize_clip(
+        st = (lib.isc_normalize_clip_nhwc4 if _nhwc4 else lib.isc_normalize_clip)(
             x.data_ptr(), _lib.dtype_code(x.dtype), b, c, h, w, mean.data_ptr(), std.data_ptr(), stat_batch,
             float(eps), lo, hi, y.data_ptr(), _lib.stream_handle(x.device),
         )

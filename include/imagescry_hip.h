@@ -89,6 +89,13 @@ int isc_channel_stats(const void* x, int dtype, int B, int C, int H, int W, floa
 int isc_normalize_clip(const void* x, int dtype, int B, int C, int H, int W, const float* mean, const float* stdev,
                        int stat_batch, float eps, float lo, float hi, float* y, void* stream);
 
+/* isc_normalize_clip written channels-last for the convolution stems: y float [B,H,W,4] with
+ * y[b][h][w][c] = the value isc_normalize_clip puts at [b][c][h][w] (bit for bit) for c < C and 0 for C <= c < 4;
+ * C <= 4.  What `Embedder.predict_step` feeds its encoder when preprocess and forward run back to back
+ * (src/imagescry/models/embedding.py:70-72): one pass instead of normalise (NCHW) + isc_nchw_to_nhwc. */
+int isc_normalize_clip_nhwc4(const void* x, int dtype, int B, int C, int H, int W, const float* mean, const float* stdev,
+                             int stat_batch, float eps, float lo, float hi, float* y, void* stream);
+
 /* Bilinear resize, align_corners=False, no antialias; the input is cast to float first.
  * Replaces `interpolate(image.float(), ..., mode="bilinear", align_corners=False)` in
  * reference src/imagescry/image/transforms.py:103-121.  Source coordinate

@@ -329,3 +329,19 @@ def test_config0_encode_then_self_search(device: torch.device) -> None:
     assert torch.allclose(scores[:, 0].cpu(), torch.ones(64), atol=1e-5)
     exp = encoder_oracle.predict_step_embeddings(images, sd)
     np.testing.assert_allclose(out.embeddings.cpu().numpy(), exp.numpy(), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["resnet50", "efficientnet_s"])
+def test_predict_step_equals_the_unfused_composition(name: str, device: torch.device) -> None:
+    """`predict_step` hands the stem a channels-last normalised batch straight from the normalisation kernel; the public
+    `preprocess` (NCHW) -> `forward` -> L2-normalise composition (reference: embedding.py:70-74) gives the same bits."""
+    from imagescry_amd import EfficientNetEmbedder, ImageBatch, ResNet50Embedder
+    from imagescry_amd.embedding import l2_normalize_channels
+
+    model = (ResNet50Embedder(seed=1) if name == "resnet50" else EfficientNetEmbedder(backbone_size="s", seed=1)).to(device)
+    images = cases.images_u8((3, 3, 70, 90)).to(device)
+    out = model.predict_step(ImageBatch(indices=torch.arange(3, device=device), images=images)).embeddings
+    ref = l2_normalize_channels(model.forward(model.preprocess(images)))
+    assert out.shape == ref.shape
+    assert torch.equal(out, ref)
+

@@ -49,6 +49,27 @@ def test_normalize_u8_vs_oracle(shape: tuple[int, ...], clip, device: torch.devi
     np.testing.assert_allclose(got.numpy(), exp.numpy(), rtol=0, atol=NORM_ATOL)
 
 
+@pytest.mark.parametrize("shape", [(8, 3, 224, 224), (3, 3, 64, 48), (2, 1, 7, 9), (1, 3, 1, 5), (5, 4, 33, 17)])
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.float32])
+def test_normalize_channels_last_is_the_same_values(shape: tuple[int, ...], dtype, device: torch.device) -> None:
+    """`_nhwc4=True` (what `predict_step` feeds the convolution stems): bit for bit the NCHW result, moved to
+    `[B, H, W, 4]` with the channels past C zero -- vectorised (H*W % 4 == 0) and scalar paths, per-image statistics."""
+    from imagescry_amd import normalize_per_channel
+
+    x = cases.images_u8(shape)
+    if dtype == torch.float32:
+        x = x.float() * 0.37 - 11.0
+    x = x.to(device)
+    b, c = shape[:2]
+    for kwargs in ({}, {"channel_means": torch.linspace(-1, 1, b * c).reshape(b, c, 1, 1).to(device),
+                        "channel_stds": torch.linspace(0.5, 2, c).reshape(1, c, 1, 1).to(device)}):
+        ref = normalize_per_channel(x, min_value=-3, max_value=3, **kwargs)
+        got = normalize_per_channel(x, min_value=-3, max_value=3, _nhwc4=True, **kwargs)
+        assert got.shape == (b, shape[2], shape[3], 4)
+        assert torch.equal(got[..., :c], ref.permute(0, 2, 3, 1))
+        assert not got[..., c:].any()
+
+
 def test_channel_statistics_are_exact_for_u8(device: torch.device) -> None:
     """u8 sums are integer-exact, so mean / unbiased std equal the float64 values rounded to float32."""
     from imagescry_amd.transforms import _channel_stats
