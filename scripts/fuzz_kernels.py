@@ -90,9 +90,13 @@ def f_resize():
 def f_conv():
     b = int(rng.integers(1, 4))
     h, w = int(rng.integers(1, 20)), int(rng.integers(1, 20))
-    cin = int(rng.choice([32, 64, 96, 160, 256]))
-    cout = int(rng.choice([4, 24, 64, 100, 128, 132, 256, 320]))
+    cin = int(rng.choice([4, 8, 24, 32, 48, 64, 80, 96, 160, 256]))  # Cin % 32 != 0: packed-K mode
+    cout = int(rng.choice([4, 24, 32, 48, 64, 100, 128, 132, 160, 192, 256, 320]))
     k = int(rng.choice([1, 1, 3, 3, 5]))
+    if rng.random() < 0.2:  # more tiles than resident workgroups: persistent walk, whole rounds + half-tile remainder
+        b, h, w = int(rng.integers(2, 9)), int(rng.integers(60, 180)), int(rng.integers(60, 180))
+        cin = int(rng.choice([8, 24, 32, 64]))
+        k = int(rng.choice([1, 3]))
     stride = int(rng.choice([1, 1, 2]))
     pad = int(rng.choice([0, k // 2]))
     if h + 2 * pad < k or w + 2 * pad < k:
@@ -108,7 +112,10 @@ def f_conv():
     fn = {"none": lambda t: t, "relu": F.relu, "silu": F.silu, "sigmoid": torch.sigmoid, "gelu": F.gelu}[act_name]
     exp = fn(y + res) if res_mode == "before" else fn(y) + (res if res is not None else 0)
     act = {"none": 0, "relu": 1, "gelu": 2, "silu": 3, "sigmoid": 4}[act_name] | (_lib.ISC_ACT_RESIDUAL_AFTER if res_mode == "after" else 0)
-    conv = FoldedConv(wt.permute(0, 2, 3, 1).contiguous().to(dev), bias.to(dev), k, stride, pad)
+    wk = wt.permute(0, 2, 3, 1).reshape(cout, k * k * cin)
+    if cin % 32:  # packed-K rows: zero-padded to whole 32-float K steps
+        wk = F.pad(wk, (0, (-wk.shape[1]) % 32))
+    conv = FoldedConv(wk.contiguous().to(dev), bias.to(dev), k, stride, pad)
     rn = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev)
     got = _conv(x.permute(0, 2, 3, 1).contiguous().to(dev), conv, act, residual=rn).permute(0, 3, 1, 2).cpu()
     err = float((got - exp).abs().max() / exp.abs().max().clamp_min(1e-30))
@@ -203,11 +210,27 @@ def f_dwconv():
     bd = bias.to(dev)
     ho, wo = exp.shape[-2:]
     out = torch.empty((b, ho, wo, c), device=dev)
-    st = lib.isc_dwconv2d_nhwc(xd.data_ptr(), b, h, w, c, wd.data_ptr(), k, stride, pad, bd.data_ptr(),
-                               {"none": 0, "relu": 1, "silu": 3}[act_name], out.data_ptr(), _lib.stream_handle(dev))
+    act = {"none": 0, "relu": 1, "silu": 3}[act_name]
+    st = lib.isc_dwconv2d_nhwc(xd.data_ptr(), b, h, w, c, wd.data_ptr(), k, stride, pad, bd.data_ptr(), act,
+                               out.data_ptr(), _lib.stream_handle(dev))
     _lib.check(st, "isc_dwconv2d_nhwc")
     got = out.permute(0, 3, 1, 2).cpu()
-    report("dwconv", torch.allclose(got, exp, rtol=1e-5, atol=1e-5), f"b{b} {h}x{w} c{c} k{k} s{stride} {act_name}: {(got - exp).abs().max():.3g}")
+    desc = f"b{b} {h}x{w} c{c} k{k} s{stride} {act_name}"
+    report("dwconv", torch.allclose(got, exp, rtol=1e-5, atol=1e-5), f"{desc}: {(got - exp).abs().max():.3g}")
+    # the pooled mean and the gated output (isc_dwconv2d_nhwc_pool); shapes without them must say so
+    gate = torch.rand(b, c, generator=g)
+    gd = gate.to(dev)
+    pooled = torch.full((b, c), float("nan"), device=dev)
+    out2 = torch.full_like(out, float("nan"))
+    st = lib.isc_dwconv2d_nhwc_pool(xd.data_ptr(), b, h, w, c, wd.data_ptr(), k, stride, pad, bd.data_ptr(), act,
+                                    gd.data_ptr(), out2.data_ptr(), pooled.data_ptr(), _lib.stream_handle(dev))
+    sweep = k == 3 and stride == 1
+    if sweep and w <= 14:
+        ok = st == 0 and torch.allclose(out2.permute(0, 3, 1, 2).cpu(), exp * gate[:, :, None, None], rtol=1e-5, atol=1e-5) \
+            and torch.allclose(pooled.cpu(), exp.mean(dim=(2, 3)), rtol=1e-5, atol=1e-6)
+        report("dwconv", ok, f"{desc} pooled + gated: status {st}")
+    else:
+        report("dwconv", st == _lib.ISC_ERR_UNSUPPORTED, f"{desc} pooled + gated outside the sweep shapes: status {st}")
 
 
 def f_gated_and_centered():
