@@ -39,6 +39,8 @@ struct ConvParams {
     int ksteps;     // R * S * cin_steps
     int act;
     int res_after_act;  // out = act(conv + bias) + residual instead of act(conv + bias + residual)
+    unsigned div_hw_mul, div_hw_sh;  // n / (Ho * Wo) = umulhi(n, mul) >> sh for n < 2^31 (conv_fastdiv); mul == 0: n itself
+    unsigned div_w_mul, div_w_sh;    // n / Wo
     int tile_base;      // this launch's tile 0 in the layer's full-tile numbering
     int tile_split;     // 1, or 2 when the launch computes half tiles (pixel halves) of the full tiles
 };
@@ -56,6 +58,21 @@ template <int V>
 struct IntTag {
     static constexpr int value = V;
 };
+
+// Division of n < 2^31 by a run-time constant d without the ~30-instruction integer division sequence (a tile's staging
+// rows need 2 * NB of them, and the persistent kernel computes them in front of a tile's last K step): with
+// l = ceil(log2 d), p = 31 + l and M = ceil(2^p / d) < 2^32, floor(n / d) = (n * M) >> p exactly for every n < 2^31.
+static void conv_fastdiv(unsigned d, unsigned* mul, unsigned* sh) {
+    if (d <= 1) { *mul = 0; *sh = 0; return; }
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    const unsigned p = 31 + l;
+    *mul = (unsigned)(((1ull << p) + d - 1) / d);
+    *sh = p - 32;
+}
+__device__ __forceinline__ int conv_div(int n, unsigned mul, unsigned sh) {
+    return mul ? (int)(__umulhi((unsigned)n, mul) >> sh) : n;
+}
 
 // a 128-byte line of zeros: the LDS-DMA source of filter taps outside the image
 __device__ __attribute__((aligned(128))) const float g_zero_line[32] = {0.f};
@@ -126,9 +143,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
         for (int i = 0; i < NB; ++i) {
             const int m = tpix0 + srow + 32 * i;
             if (m < p.M) {
-                const int b = m / (p.Ho * p.Wo);
+                const int b = conv_div(m, p.div_hw_mul, p.div_hw_sh);
                 const int rem = m - b * p.Ho * p.Wo;
-                const int ho = rem / p.Wo;
+                const int ho = conv_div(rem, p.div_w_mul, p.div_w_sh);
                 const int wo = rem - ho * p.Wo;
                 b_img[i] = b;
                 b_base[i] = b * p.H * p.W * p.Cin + (TAP4 ? 0 : lchunk * 4);
@@ -893,6 +910,8 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     p.x = x; p.w = w; p.bias = bias; p.res = residual; p.sub = sub; p.scale = scale; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = tap4 ? 1 : Cin / 32; p.cin4 = Cin / 4; p.ksteps = ksteps; p.act = act; p.res_after_act = res_after_act; p.tile_base = 0; p.tile_split = 1;
+    conv_fastdiv((unsigned)(Ho * Wo), &p.div_hw_mul, &p.div_hw_sh);
+    conv_fastdiv((unsigned)Wo, &p.div_w_mul, &p.div_w_sh);
     hipStream_t s = isc_stream(stream);
     // 64-channel tiles wherever they pad Cout less than 128-channel ones do (Cout <= 64, but also 160 -> 192 instead of
     // 256, 192 -> 192 instead of 256): the wasted quarter of the matrix work is worth more than the extra tile reloads
