@@ -116,6 +116,15 @@ constexpr int forced_tile() { return 0; }
 // seen so far lets about kp * (R - 1) rows per query pass the threshold (the kp-th best score of those earlier rows --
 // the bank is stored in a pseudo-random row order, so earlier rows are an even sample); R is chosen so that this stays
 // below half the per-query list AND below 1/8 of what the lane-private segments of the level hold together.
+#ifdef ISC_ABLATION
+int first_ratio() {
+    static const int v = getenv("ISC_FIRST_RATIO") ? atoi(getenv("ISC_FIRST_RATIO")) : 16;  // A/B aid; 1 << 20 = off
+    return v;
+}
+#else
+constexpr int first_ratio() { return 16; }
+#endif
+
 Plan make_plan(int64_t n, int q, int k) {
     Plan p;
     p.qb = q < QBATCH ? q : QBATCH;
@@ -155,6 +164,13 @@ Plan make_plan(int64_t n, int q, int k) {
         int64_t budget = QCAP / 2;
         if (nseg * CAP / 8 < budget) budget = nseg * CAP / 8;
         int64_t ratio = 1 + budget / p.kp;
+        // 256-query shape with ONE query tile (128 < Q <= 256): the level after the sample would be the whole bank on
+        // the sample's weak threshold -- a wave's ballot over 128 rows x 16 queries trips with probability
+        // 1 - exp(-2048 kp / rows seen), 39 % after 65 536 rows, and every trip is a scan of the block.  A short
+        // intermediate level buys a threshold that trips 3 % for the price of one k_select: 10 M rows at Q = 256
+        // 4.17 -> 4.00 ms (scripts/ab_first_ratio.sh).  With four query tiles (Q = 1024) the same level costs more than it
+        // saves (13.34 -> 13.67 ms at ratio 8, no change at 16), so it is not used there.
+        if (p.tnq == 256 && p.qtiles == 1 && p.nlevels == 1 && ratio > first_ratio()) ratio = first_ratio();
         if (ratio < 3) ratio = 3;
         int64_t r1 = seen * ratio;  // multiple of TM because `seen` is
         if (r1 > n || p.nlevels == MAX_LEVELS - 1) r1 = n;
