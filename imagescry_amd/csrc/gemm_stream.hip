@@ -151,11 +151,15 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
     const int srow = SPLIT ? (tid & 255) >> 3 : tid >> 3;
     const int spc = tid & 7;
     const int sw16 = (spc ^ ((srow >> 1) & 7)) << 4;
-    const int wperm = 16 * ((srow & 15) >> 2) + 4 * (srow >> 4) + (srow & 3);
+    // float32 output keeps the NATURAL order (MFMA block n = features 16 n .. 16 n + 15, a lane's four values of block n
+    // are features 16 n + 4 fg + j): a store / residual-load instruction then covers 64 contiguous bytes per token row
+    // (four lanes x 16 B) instead of four 16-byte pieces 64 bytes apart, which is what the permutation gives it
+    constexpr bool NATURAL = EPI == EPI_F32 && DBG == 0;
+    const int wperm = NATURAL ? srow : 16 * ((srow & 15) >> 2) + 4 * (srow >> 4) + (srow & 3);
     const unsigned char* a_stream = p.a + (int64_t)tile_begin * ksteps * TILE_BYTES + srow * 128 + sw16;
     const unsigned char* b_stream = p.w + (int64_t)fb * ksteps * TILE_BYTES + wperm * 128 + sw16;
     // byte offset of staging round i inside a weight K-step block (SPLIT): rows 64 (i >> 1) + 8 (i & 1)
-    auto wround = [](int i) { return (64 * (i >> 1) + 8 * (i & 1)) * 128; };
+    auto wround = [](int i) { return NATURAL ? 32 * i * 128 : (64 * (i >> 1) + 8 * (i & 1)) * 128; };
 
     unsigned char* const lds_a = lds;
     unsigned char* const lds_b = lds + A_ST * TILE_BYTES;
@@ -215,12 +219,13 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
     const int a_wave_off = wm * (GT / WM) * 128;
     const int b_wave_off = wn * 64 * 128;
 
-    // this lane's 16 features: nb + 4 n + r
-    const int nb = fb * GT + wn * 64 + fg * 16;
+    // this lane's 16 features: nb + NS n + r  (permuted: 16 contiguous features; natural: four groups 16 apart)
+    constexpr int NS = NATURAL ? 16 : 4;
+    const int nb = fb * GT + wn * 64 + fg * (NATURAL ? 4 : 16);
     f32x4 bias[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n)
-        bias[n] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bias[n] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + NS * n) : f32x4{0.f, 0.f, 0.f, 0.f};
     // the bias loads above are ordinary vector-memory operations: drain them before the DMA ring starts counting
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3])::"memory");
 
@@ -258,13 +263,13 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
                 if (p.res) {
                     f32x4 rr[4];
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) rr[n] = *reinterpret_cast<const f32x4*>(p.res + o + 4 * n);
+                    for (int n = 0; n < 4; ++n) rr[n] = *reinterpret_cast<const f32x4*>(p.res + o + NS * n);
 #pragma unroll
                     for (int n = 0; n < 4; ++n) c[n] += rr[n];
                 }
                 float* dst = reinterpret_cast<float*>(p.out) + o;
 #pragma unroll
-                for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(dst + 4 * n) = c[n];
+                for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(dst + NS * n) = c[n];
             }
         } else {
             // packed fp16 output: the buffer holds whole 256-row tiles, rows past M are padding nobody reads -- the two
