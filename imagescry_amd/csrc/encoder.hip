@@ -1,5 +1,6 @@
-// Encoder blocks in float32 (include/imagescry_hip.h: isc_conv2d_nhwc, isc_im2col_nchw, isc_maxpool_nhwc,
-// isc_global_avgpool_nhwc, isc_nchw_to_nhwc).
+// Encoder blocks in float32 (include/imagescry_hip.h: isc_conv2d_nhwc, isc_conv2d_nhwc_gated, isc_linear_centered,
+// isc_dwconv2d_nhwc, isc_dwconv2d_nhwc_pool, isc_se_gate, isc_im2col_nchw, isc_maxpool_nhwc, isc_global_avgpool_nhwc,
+// isc_nchw_to_nhwc).
 //
 // isc_conv2d_nhwc is an implicit GEMM on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact float32 products
 // and a k-ordered fma chain, so results agree with a CPU float32 convolution to rounding):
@@ -12,8 +13,12 @@
 // operand (rows = output channels) and the pixel tile the "B" operand (columns = output pixels): a lane then owns
 // four CONSECUTIVE output channels of one pixel, i.e. one 16-byte store into the NHWC output, and bias /
 // residual are 16-byte loads.  LDS tiles are [rows][128 B] with the 16-byte chunks XOR-swizzled by (row >> 1) & 7
-// (conflict-free ds_read_b128 fragment reads), double buffered, one barrier per K step, next step prefetched
-// into registers while the current one is on the matrix cores.
+// (conflict-free ds_read_b128 fragment reads), double buffered, one barrier per K step; the next step is staged by
+// LDS-DMA (or, when x needs a per-element transform, prefetched into registers) while the current one is on the matrix
+// cores.  The LDS-DMA kernels are persistent (two workgroups per CU walk the tiles); see k_conv_f32 and conv_launch.
+//
+// Also here: the depthwise row-sweep kernel and the squeeze-excitation gate of the MBConv blocks (k_dwconv3x3_rows,
+// k_se_gate), pooling and layout kernels.
 #include <stdlib.h>
 
 #include "isc_common.h"
