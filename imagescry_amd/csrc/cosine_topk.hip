@@ -117,6 +117,7 @@ constexpr int forced_tile() { return 0; }
 // the bank is stored in a pseudo-random row order, so earlier rows are an even sample); R is chosen so that this stays
 // below half the per-query list AND below 1/8 of what the lane-private segments of the level hold together.
 #ifdef ISC_ABLATION
+__device__ int g_abl_thr_inf = 0;  // set from ISC_THR_INF by run(): every non-sample level filters against +inf (wrong results)
 int first_ratio() {
     static const int v = getenv("ISC_FIRST_RATIO") ? atoi(getenv("ISC_FIRST_RATIO")) : 16;  // A/B aid; 1 << 20 = off
     return v;
@@ -388,6 +389,9 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     for (int n = 0; n < 4; ++n) {
         thr[n] = tau[q0 + wn * 64 + n * 16 + frow];
         if ((DBG != 0 && DBG < 11) || DBG >= 15) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
+#ifdef ISC_ABLATION
+        if (!SAMPLE && g_abl_thr_inf) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ISC_THR_INF: the price of scanning + the tail
+#endif
         cnt[n] = 0;
     }
 
@@ -707,24 +711,44 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             // copy of a duplicated row, through and overflowed the buffers.
             kt = 0;
             const int64_t trow0 = r0 + (int64_t)(tile_begin + tile) * TM + wm * (TM / WM) + fg * 4;
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                float mx = -INFINITY;
+            // rows past the end of the level exist only in its last tile: they become -inf there, once, instead of
+            // being tested per element
+            if (r0 + (int64_t)(tile_begin + tile + 1) * TM > r1) {
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
-                    mx = fmaxf(mx, fmaxf(fmaxf(acc[m][n][0], acc[m][n][1]), fmaxf(acc[m][n][2], acc[m][n][3])));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (trow0 + m * 16 + r >= r1) {
+#pragma unroll
+                            for (int n = 0; n < 4; ++n) acc[m][n][r] = -INFINITY;
+                        }
+            }
+            // Two-stage test per query column block: the maximum over the lane's 32 scores decides (one ballot) whether
+            // anything is scanned at all; then the eight row-block maxima decide block by block, so a trip costs eight
+            // ballots plus four compares per block that really holds a survivor instead of 32 branchy compares (on the
+            // sample's threshold, 86 % of the first level's tiles trip: the scan was 17 % of that level).
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                float bm[MB];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    bm[m] = fmaxf(fmaxf(acc[m][n][0], acc[m][n][1]), fmaxf(acc[m][n][2], acc[m][n][3]));
+                    mx = fmaxf(mx, bm[m]);
+                }
                 if (__ballot(mx > thr[n]) != 0ull) {
 #pragma unroll
-                    for (int m = 0; m < MB; ++m)
+                    for (int m = 0; m < MB; ++m) {
+                        if (__ballot(bm[m] > thr[n]) == 0ull) continue;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float s = acc[m][n][r];
-                            const int64_t row = trow0 + m * 16 + r;
-                            if (s > thr[n] && row < r1) {
+                            if (s > thr[n]) {
                                 const int pos = cnt[n]++;
-                                if (pos < CAP) my_ent[(size_t)n * 16 * CAP + pos] = Cand{s, (int32_t)row};
+                                if (pos < CAP) my_ent[n * 16 * CAP + pos] = Cand{s, (int32_t)(trow0 + m * 16 + r)};
                             }
                         }
+                    }
                 }
             }
 #pragma unroll
@@ -1261,6 +1285,8 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
     static const bool force_split = getenv("ISC_FORCE_SPLIT") != nullptr;
     static const int prio = getenv("ISC_NO_STATIC_PRIO") ? 1 : 0;  // A/B aid: bit 18 of nslots switches the priority off
     nslots_arg |= prio << 18;
+    static const int fabl = getenv("ISC_FILTER_ABL") ? atoi(getenv("ISC_FILTER_ABL")) : 0;  // 2: filter launches skip the tail
+    nslots_arg |= (fabl & 3) << 16;
     if (mode == 0 && TNQ == 256 && p.qtiles > 1 && !force_split) mode = 12;
 #else
     if (mode == 0 && TNQ == 256 && p.qtiles > 1) mode = 12;
@@ -1291,6 +1317,13 @@ template <typename T>
 int run(const void* bank, int64_t n, int d, const void* queries, int q_total, int64_t ldq, int k, int64_t index_base,
         const float* norm_bound, float* out_s, int64_t* out_i, int32_t* status, void* ws_base, hipStream_t stream) {
     const Plan p = make_plan(n, q_total, k);
+#ifdef ISC_ABLATION
+    static const bool thr_inf_set = [] {
+        const int v = getenv("ISC_THR_INF") != nullptr;
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_abl_thr_inf), &v, sizeof(int)) == hipSuccess;
+    }();
+    (void)thr_inf_set;
+#endif
     const int ksteps = isc_ksteps(d, (int)sizeof(T));
     const Workspace w = carve(p, ksteps, n, k, ws_base);
     const unsigned char* bank_bytes = static_cast<const unsigned char*>(bank);
