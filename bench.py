@@ -612,12 +612,12 @@ def main() -> None:
         torch.cuda.empty_cache()
         secondary = secondary_vit = secondary_eff = None
         if not args.no_secondary and rank == 0:
-            secondary = bench_encode(args, rank, world, device, steps=3, warmup=1, collective_timing=False)
+            secondary = bench_encode(args, rank, world, device, steps=6, warmup=2, collective_timing=False)
             secondary.pop("_model"), secondary.pop("_images")
             torch.cuda.empty_cache()
-            secondary_vit = bench_encode_vit(args, device, steps=3, warmup=1)
+            secondary_vit = bench_encode_vit(args, device, steps=6, warmup=2)
             torch.cuda.empty_cache()
-            secondary_eff = bench_encode_efficientnet(args, device, steps=3, warmup=1)
+            secondary_eff = bench_encode_efficientnet(args, device, steps=6, warmup=2)
     elif args.workload == "pipeline":
         primary = bench_pipeline(args, rank, world, device)
         secondary = secondary_vit = secondary_eff = None
