@@ -734,11 +734,32 @@ __global__ __launch_bounds__(256) void k_global_avgpool_nhwc(const float* __rest
 // row, 64 / LPR rows per load instruction, four instructions in flight; the squeezed vector stays in LDS and every
 // weight load serves IMG images.
 constexpr int SE_THREADS = 1024;
+
+// Sum over aligned groups of `width` lanes (a power of two, wave-uniform), left in every lane of the group.  Within a
+// 16-lane row the exchange is a DPP modifier on the add (quad permutes, then the half-row and row mirrors -- any pairing
+// of the right sub-groups does for a sum); only widths above 16 go through the LDS permute unit.  With __shfl_xor at
+// every step (a ds_bpermute and its latency each) the reductions were three quarters of k_se_gate's fc2 phase.
+template <int CTRL>
+__device__ __forceinline__ float se_dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float se_group_sum(float v, int width) {
+    if (width > 1) v = se_dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    if (width > 2) v = se_dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    if (width > 4) v = se_dpp_add<0x141>(v);  // row_half_mirror
+    if (width > 8) v = se_dpp_add<0x140>(v);  // row_mirror
+    for (int off = 16; off < width; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
 template <int IMG>
 __global__ __launch_bounds__(SE_THREADS) void k_se_gate(const float* __restrict__ pooled, int B, int C,
                                                         const float* __restrict__ w1, int ld1, const float* __restrict__ b1,
                                                         int S, const float* __restrict__ w2, int ld2,
                                                         const float* __restrict__ b2, int lpr, float* __restrict__ gate) {
+#ifdef ISC_ABLATION
+    const int se_abl = lpr >> 16;  // timing aids (wrong results): 1 = stop after fc1, 2 = skip fc1
+    lpr &= 0xffff;
+#endif
     extern __shared__ __attribute__((aligned(16))) float se_lds[];
     float* sx = se_lds;            // [IMG][C]
     float* sq = se_lds + IMG * C;  // [IMG][S]
@@ -757,6 +778,11 @@ __global__ __launch_bounds__(SE_THREADS) void k_se_gate(const float* __restrict_
     }
     __syncthreads();
     // fc1: outputs n0 + {0, NW, 2 NW, 3 NW} of this wave together
+#ifdef ISC_ABLATION
+    if (se_abl == 2) {
+        for (int i = tid; i < IMG * S; i += SE_THREADS) sq[i] = 0.5f;
+    } else
+#endif
     for (int n0 = wave; n0 < S; n0 += 4 * NW) {
         float acc[4][IMG];
 #pragma unroll
@@ -789,9 +815,7 @@ __global__ __launch_bounds__(SE_THREADS) void k_se_gate(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int im = 0; im < IMG; ++im)
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) acc[j][im] += __shfl_xor(acc[j][im], off, 64);
+            for (int im = 0; im < IMG; ++im) acc[j][im] = se_group_sum(acc[j][im], 64);
         if (lane == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -804,6 +828,9 @@ __global__ __launch_bounds__(SE_THREADS) void k_se_gate(const float* __restrict_
         }
     }
     __syncthreads();
+#ifdef ISC_ABLATION
+    if (se_abl == 1) return;
+#endif
     // fc2: lane = (row r of the load, 16-byte piece s4 of the row)
     const int svec = S / 4;
     const int rpl = 64 / lpr;
@@ -814,7 +841,7 @@ __global__ __launch_bounds__(SE_THREADS) void k_se_gate(const float* __restrict_
 #pragma unroll
     for (int im = 0; im < IMG; ++im) qv[im] = s_ok ? *reinterpret_cast<const f32x4*>(sq + im * S + s4 * 4) : zero;
     const int step = NW * rpl;  // rows per round of the workgroup
-    constexpr int NR = 8;  // weight loads in flight per lane
+    constexpr int NR = 8;  // weight loads in flight per lane (12 measured slower)
     for (int c0 = wave * rpl + r; c0 < C + (NR - 1) * step; c0 += NR * step) {
         f32x4 wv[NR];
 #pragma unroll
@@ -831,15 +858,25 @@ __global__ __launch_bounds__(SE_THREADS) void k_se_gate(const float* __restrict_
                 acc[im] = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[im] = fmaf(wv[j][e], qv[im][e], acc[im]);
-                for (int off = lpr >> 1; off >= 1; off >>= 1) acc[im] += __shfl_xor(acc[im], off, 64);
+                acc[im] = se_group_sum(acc[im], lpr);
             }
+            // the pooled vector is no longer needed: its LDS takes the pre-activation gate, written out below as whole
+            // 16-byte pieces by all lanes (four lanes per wave storing 4 bytes each was a quarter of this phase)
             if (s4 == 0 && c < C) {
-                const float bias = b2 ? b2[c] : 0.f;
 #pragma unroll
-                for (int im = 0; im < IMG; ++im)
-                    if (img0 + im < B) gate[(size_t)(img0 + im) * C + c] = apply_act(acc[im] + bias, ISC_ACT_SIGMOID);
+                for (int im = 0; im < IMG; ++im) sx[im * C + c] = acc[im];
             }
         }
+    }
+    __syncthreads();
+    for (int i = tid; i < IMG * cvec; i += SE_THREADS) {
+        const int im = i / cvec, c4 = i - im * cvec;
+        if (img0 + im >= B) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(sx + im * C + c4 * 4);
+        if (b2) v += *reinterpret_cast<const f32x4*>(b2 + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], ISC_ACT_SIGMOID);
+        *reinterpret_cast<f32x4*>(gate + (size_t)(img0 + im) * C + c4 * 4) = v;
     }
 }
 
@@ -1112,12 +1149,18 @@ extern "C" int isc_se_gate(const float* pooled, int B, int C, const float* w1, i
                            const float* w2, int ld2, const float* b2, float* gate, void* stream) {
     ISC_REQUIRE(pooled && w1 && w2 && gate && B > 0 && C > 0 && S > 0 && ld1 >= C && ld2 >= S);
     if (C % 4 != 0 || S % 4 != 0 || ld1 % 4 != 0 || ld2 % 4 != 0) return ISC_ERR_UNSUPPORTED;
-    if (!isc_aligned(pooled, 16) || !isc_aligned(w1, 16) || !isc_aligned(w2, 16)) return ISC_ERR_ALIGNMENT;
+    if (!isc_aligned(pooled, 16) || !isc_aligned(w1, 16) || !isc_aligned(w2, 16) || !isc_aligned(gate, 16) ||
+        (b2 && !isc_aligned(b2, 16)))
+        return ISC_ERR_ALIGNMENT;
     constexpr int IMG = 2;  // measured: 1 -> 54 us, 2 -> 45 us, 4 -> 72 us per launch at C = 1536, S = 64, B = 512
     const size_t lds = (size_t)IMG * ((size_t)C + S) * sizeof(float);
     if (lds > 64 * 1024 || S > 256) return ISC_ERR_UNSUPPORTED;  // C + S <= 16384, S <= 256
     int lpr = 1;
     while (lpr < S / 4) lpr *= 2;  // lanes along a w2 row
+#ifdef ISC_ABLATION
+    static const int se_abl = getenv("ISC_SE_ABL") ? atoi(getenv("ISC_SE_ABL")) : 0;
+    lpr |= se_abl << 16;
+#endif
     hipLaunchKernelGGL((k_se_gate<IMG>), dim3((unsigned)isc_ceil_div(B, IMG)), dim3(SE_THREADS), lds, isc_stream(stream),
                        pooled, B, C, w1, ld1, b1, S, w2, ld2, b2, lpr, gate);
     return isc_launch_status();
