@@ -8,11 +8,12 @@
 
 // ---- (score, row) as one 64-bit key whose unsigned order is the search order ------------------------------------
 // larger key = better candidate: higher score first, then LOWER row.  Keys of distinct rows are distinct.  A NaN
-// score ranks below every number (the oracle's lexsort puts NaN last).  0 is "empty": a real entry has row <=
-// 2^31 - 2, so its low word is >= 1.
+// score ranks below every number (the oracle's lexsort puts NaN last), and -0.0 is the same score as +0.0 (as it is to
+// the oracle's comparison: a zero query scores -0.0 against a row with no positive entry, and that row ties every
+// other).  0 is "empty": a real entry has row <= 2^31 - 2, so its low word is >= 1.
 __device__ __forceinline__ unsigned isc_score_bits(float s) {
     if (s != s) return 0u;
-    unsigned u = __float_as_uint(s);
+    unsigned u = s == 0.f ? 0u : __float_as_uint(s);  // the bits of +0.0 for both zeros
     u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;  // monotone float -> unsigned; -inf -> 0x007fffff
     return u;
 }

@@ -95,6 +95,33 @@ def test_zero_query_and_unpadded_dim(device: torch.device) -> None:
     assert scores[1].abs().max().item() == 0.0
 
 
+def test_signed_zero_scores_are_one_score(device: torch.device) -> None:
+    """A zero query scores -0.0 against a bank row without a positive entry and +0.0 against the others; both are the
+    score 0 (to the oracle's comparison and to torch.topk alike), so the answer is rows 0..k-1 -- in the fast path, in the
+    exact pass and in the merge of partial lists."""
+    from imagescry_amd import EmbeddingBank, _lib
+
+    bank, queries = cases.search_case(3000, 64, 3, torch.float16)
+    bank[::3] = -bank[::3].abs()  # every third row: no positive entry
+    queries[1] = 0
+    exp_s, exp_i = search_oracle.cosine_topk(bank, queries, 12)
+    eb = EmbeddingBank(bank.to(device), dtype=torch.float16, normalize=False)
+    for search in (eb.search, eb.search_exhaustive):
+        scores, indices = search(queries.to(device), 12)
+        _check(scores, indices, exp_s, exp_i)
+        assert indices[1].cpu().tolist() == list(range(12))
+    # the merge kernel on its own: partial lists holding both zeros
+    sc = torch.tensor([[[0.0, -0.0, -1.0]], [[-0.0, 0.0, -2.0]]])  # [G = 2, Q = 1, kin = 3]
+    ix = torch.tensor([[[7, 3, 100]], [[5, 9, 101]]], dtype=torch.int64)
+    out_s = torch.empty((1, 5), device=device)
+    out_i = torch.empty((1, 5), dtype=torch.int64, device=device)
+    sd, idd = sc.to(device), ix.to(device)
+    _lib.check(_lib.load().isc_topk_merge(sd.data_ptr(), idd.data_ptr(), 2, 1, 3, 5, 0, 0, out_s.data_ptr(),
+                                          out_i.data_ptr(), _lib.stream_handle(device)), "isc_topk_merge")
+    assert out_i.cpu().tolist() == [[3, 5, 7, 9, 100]]
+    assert out_s.cpu().tolist() == [[0.0, 0.0, 0.0, 0.0, -1.0]]
+
+
 def test_bank_normalisation_and_fp32_queries(device: torch.device) -> None:
     """`normalize=True` applies the F.normalize formula before the cast; float32 queries are cast to the bank dtype."""
     g = cases.gen(5)
