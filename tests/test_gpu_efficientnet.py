@@ -199,6 +199,23 @@ def test_efficientnet_s_forward_matches_oracle(shape: tuple[int, ...], device: t
     assert err < 5e-5, err
 
 
+@pytest.mark.parametrize("size", ["m", "l"])
+def test_efficientnet_m_l_forward_matches_oracle(size: str, device: torch.device) -> None:
+    """The wider variants: channel counts that are not multiples of 32 (80, 176, 304 in "m": packed-K mode), squeeze
+    widths up to 160, expanded widths up to 3840 in the SE gate kernel."""
+    from imagescry_amd import EfficientNetEmbedder, efficientnet
+
+    sd = efficientnet.make_state_dict(size, seed=7, randomize_bn=True)
+    model = EfficientNetEmbedder(backbone_size=size, state_dict=sd).to(device)
+    x = torch.randn((1, 3, 64, 96), generator=cases.gen(11)).clip(-3, 3)
+    with torch.no_grad():
+        exp = efficientnet_oracle.features(x, sd, _stages(size))
+    got = model.forward(x.to(device)).cpu()
+    assert got.shape == exp.shape == (1, 1280, 2, 3)
+    err = float((got - exp).abs().max() / exp.abs().max())
+    assert err < 5e-5, err
+
+
 def test_efficientnet_predict_step_matches_oracle(device: torch.device) -> None:
     from imagescry_amd import EfficientNetEmbedder, ImageBatch, efficientnet
 
