@@ -34,10 +34,29 @@ __device__ __forceinline__ unsigned long long isc_bcast_key(unsigned long long k
     const unsigned hi = __builtin_amdgcn_readlane((unsigned)(k >> 32), src_lane);
     return ((unsigned long long)hi << 32) | lo;
 }
+// Maximum over the wave, left in every lane.  Inside a 16-lane row the partner's key comes through a DPP move (quad
+// permutes, then the half-row and row mirrors: any exchange that pairs the right sub-groups does for a maximum); only
+// the two steps across rows go through the LDS permute unit.  k_select / k_final call this kp times per query to peel
+// off the kp largest lane maxima: with __shfl_xor at all six steps that was a third of k_select's time at Q <= 64.
+template <int CTRL>
+__device__ __forceinline__ void isc_key_max_dpp(unsigned& lo, unsigned& hi) {
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, true);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, true);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+    if (o > m) {
+        lo = olo;
+        hi = ohi;
+    }
+}
 __device__ __forceinline__ unsigned long long isc_wave_max_key(unsigned long long k) {
     unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+    isc_key_max_dpp<0xB1>(lo, hi);   // quad_perm [1,0,3,2]
+    isc_key_max_dpp<0x4E>(lo, hi);   // quad_perm [2,3,0,1]
+    isc_key_max_dpp<0x141>(lo, hi);  // row_half_mirror
+    isc_key_max_dpp<0x140>(lo, hi);  // row_mirror
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 16; off <= 32; off <<= 1) {
         const unsigned olo = __shfl_xor(lo, off, 64), ohi = __shfl_xor(hi, off, 64);
         const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
         const unsigned long long m = ((unsigned long long)hi << 32) | lo;
