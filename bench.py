@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark of the embed-and-search hot path on MI355X (contract: see the build prompt / DESIGN.md).
 
-    python bench.py --gpus N --steps K --warmup W            # N = 1
+    python bench.py --gpus N --steps K --warmup W            # any N: for N > 1 without a launcher (WORLD_SIZE unset)
+                                                             # it starts the N ranks itself (torch.distributed.run child)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W                 # N > 1, one rank per GPU over RCCL
 
@@ -27,12 +28,45 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
 
-import torch
-import torch.distributed as dist
+
+def _self_launch() -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks here, as ONE
+    child `python -m torch.distributed.run ... bench.py <same arguments>`, and exit with its code.  This runs before
+    torch or the HIP library is imported: the parent never touches a GPU (a process that has initialised HIP must not
+    spawn the ranks' runtime), it only waits."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    gpus = 1
+    argv = sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            gpus = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            gpus = int(a.split("=", 1)[1])
+    if gpus <= 1:
+        return
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print(f"bench.py: WORLD_SIZE unset, starting {gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+if __name__ == "__main__":
+    _self_launch()
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
@@ -71,12 +105,15 @@ def setup_dist(args: argparse.Namespace) -> tuple[int, int, torch.device]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    if world != args.gpus:  # a launcher started a different number of ranks than asked for
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     # ISC_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share devices)
     backend = os.environ.get("ISC_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} over RCCL needs {world} devices, {torch.cuda.device_count()} visible "
+                         f"(ISC_BENCH_BACKEND=gloo rehearses the path with ranks sharing a device)")
     device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     if world > 1:
@@ -139,7 +176,8 @@ def selfcheck(shard: torch.Tensor, lo: int, queries: torch.Tensor, scores: torch
     """Proof, on the device and outside the timed region, that (scores, indices) is the cosine top-k of `queries` over
     the WHOLE bank, each rank vouching for its shard (rows [lo, lo + len(shard)), row-major):
       identical      every rank holds the same merged result (min == max of a checksum over the ranks);
-      scores_exact   the scores of the returned rows this rank owns equal their float64 cosine (to float32 rounding);
+      scores_exact   the scores of the returned rows this rank owns equal float32(their float64 cosine) BIT FOR BIT
+                     (`scores_max_abs_diff` reports the largest difference, 0.0 when exact);
       kth_is_kth     the rows of this shard that rank before the k-th entry (score desc, index asc), summed over the
                      ranks, are exactly k - 1 per query -- nothing outside the answer beats it, nothing is missing;
       sorted         every result row is ordered."""
@@ -153,7 +191,8 @@ def selfcheck(shard: torch.Tensor, lo: int, queries: torch.Tensor, scores: torch
     qi, ki = mine.nonzero(as_tuple=True)
     rows = shard[indices[qi, ki] - lo].double()
     exact = ((rows * q64[qi]).sum(dim=1) / denom[qi]).float()
-    exact_ok = bool(torch.equal(exact, scores[qi, ki])) or bool((exact - scores[qi, ki]).abs().max() <= 1e-7)
+    exact_ok = bool(torch.equal(exact, scores[qi, ki]))  # bit for bit: the search's scores ARE float32(float64 cosine)
+    max_diff = float((exact.double() - scores[qi, ki].double()).abs().max()) if exact.numel() else 0.0
     kth, kth_idx = s64[:, -1], indices[:, -1]
     ahead = torch.zeros(q, dtype=torch.int64, device=device)
     blk = 1 << 17
@@ -165,21 +204,24 @@ def selfcheck(shard: torch.Tensor, lo: int, queries: torch.Tensor, scores: torch
     checksum = ((indices * w).sum() + (scores.view(torch.int32).long() * w).sum()).reshape(1)
     cmin, cmax = checksum.clone(), checksum.clone()
     flags = torch.tensor([int(sorted_ok), int(exact_ok)], dtype=torch.int64, device=device)
+    diff = torch.tensor([max_diff], dtype=torch.float64, device=device)
     if world > 1:
         cd = _collective_device(device)
-        ahead, cmin, cmax, flags = ahead.to(cd), cmin.to(cd), cmax.to(cd), flags.to(cd)
+        ahead, cmin, cmax, flags, diff = ahead.to(cd), cmin.to(cd), cmax.to(cd), flags.to(cd), diff.to(cd)
         dist.all_reduce(ahead, op=dist.ReduceOp.SUM)
         dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        dist.all_reduce(diff, op=dist.ReduceOp.MAX)
     out = {
         "identical_on_all_ranks": bool((cmin == cmax).item()),
         "scores_exact": bool(flags[1].item()),
+        "scores_max_abs_diff": float(diff.item()),
         "kth_is_kth": bool((ahead == k - 1).all().item()),
         "sorted": bool(flags[0].item()),
         "checksum": int(cmin.item()),
     }
-    out["ok"] = all(v for v in out.values() if isinstance(v, bool))
+    out["ok"] = all(v for v in out.values() if isinstance(v, bool))  # floats (the diff) are reported, not judged
     return out
 
 
@@ -302,14 +344,23 @@ def bench_search(args: argparse.Namespace, rank: int, world: int, device: torch.
     bank = EmbeddingBank(shard, dtype=torch.float16, normalize=False, index_base=lo, process_group=group,
                          presharded=True)
 
+    pending: list = []
+
     def step() -> None:
-        bank.search(queries, k)
+        # a stream of searches: search i is enqueued, THEN the handle of search i - 1 is resolved on this stream, so on
+        # a sharded bank the all-gather + merge of i - 1 (the bank's exchange stream) run under the local kernels of i.
+        # The closing fence synchronises the whole device, i.e. the last exchange too.
+        pending.append(bank.search_async(queries, k))
+        if len(pending) > 1:
+            pending.pop(0).result()
 
     for _ in range(args.warmup):
         step()
     _lib.timing_enable(True)
     _lib.timing_read(_lib.ISC_KERNEL_DOTS_FILTER)
     seconds = timed_steps(step, args.steps, 0, world, device)
+    while pending:
+        pending.pop(0).result()
     kernel_ms, launches = _lib.timing_read(_lib.ISC_KERNEL_DOTS_FILTER)
     _lib.timing_enable(False)
     status = bank.last_status.cpu().tolist()

@@ -25,7 +25,7 @@ from imagescry_amd.embedding import (
     l2_normalize_channels,
 )
 from imagescry_amd.pipelines import EmbeddingPCAPipeline, EmbedSearchPipeline, SearchResult
-from imagescry_amd.search import EmbeddingBank, shard_bounds
+from imagescry_amd.search import EmbeddingBank, SearchHandle, shard_bounds
 from imagescry_amd.transforms import normalize_per_channel, resize, to_4d
 
 __all__ = [
@@ -35,6 +35,7 @@ __all__ = [
     "EmbeddingModule",
     "EmbeddingPCAPipeline",
     "EmbedSearchPipeline",
+    "SearchHandle",
     "SearchResult",
     "PCA",
     "ResNet50Embedder",

@@ -17,7 +17,8 @@ import torch
 
 LIB_NAME = "libimagescry_hip.so"
 # ISC_LIB selects another build of the same ABI (the -DISC_ABLATION library used by scripts/ for ablation runs); it is
-# never set in production
+# never set in production, and `load()` refuses a library that reports ISC_BUILD_ABLATION unless ISC_ALLOW_ABLATION=1 is
+# set as well (its ISC_DEBUG_MODE-style variants return wrong results by design)
 LIB_PATH = Path(os.environ.get("ISC_LIB") or Path(__file__).resolve().parent / LIB_NAME)
 
 ISC_U8, ISC_F16, ISC_F32 = 0, 1, 2
@@ -25,7 +26,9 @@ ISC_ACT_NONE, ISC_ACT_RELU, ISC_ACT_GELU, ISC_ACT_SILU, ISC_ACT_SIGMOID = 0, 1, 
 ISC_ACT_RESIDUAL_AFTER = 0x100
 ISC_TOPK_MAX_K = 120
 ISC_SEARCH_MAX_D = 8192
-ISC_ABI_VERSION = 2
+ISC_SEARCH_PASS_QUERIES = 1024  # queries per pass of isc_cosine_topk (the workspace is sized for one pass)
+ISC_ABI_VERSION = 3
+ISC_BUILD_ABLATION = 1
 ISC_GEMM_A_PACKED, ISC_GEMM_W_PACKED, ISC_GEMM_OUT_PACKED, ISC_GEMM_TILE_256, ISC_GEMM_TILE_128 = 1, 2, 4, 8, 16
 ISC_KERNEL_DOTS_FILTER, ISC_KERNEL_CONV, ISC_KERNEL_GEMM_F16 = 0, 1, 2
 
@@ -45,6 +48,7 @@ class HipLibraryError(RuntimeError):
 # name -> (restype, argtypes); every symbol include/imagescry_hip.h declares
 SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "isc_abi_version": (c_int, []),
+    "isc_build_flags": (c_int, []),
     "isc_strerror": (c_char_p, [c_int]),
     "isc_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
     "isc_timing_enable": (c_int, [c_int]),
@@ -163,6 +167,11 @@ def load() -> ctypes.CDLL:
         raise HipLibraryError(
             f"ABI version mismatch: library reports {lib.isc_abi_version()}, binding expects {ISC_ABI_VERSION}; "
             "rebuild it with `python -m imagescry_amd.build`"
+        )
+    if lib.isc_build_flags() & ISC_BUILD_ABLATION and os.environ.get("ISC_ALLOW_ABLATION") != "1":
+        raise HipLibraryError(
+            f"{LIB_PATH} is an ablation build (-DISC_ABLATION: timing variants that return wrong results); it is only "
+            "loaded with ISC_ALLOW_ABLATION=1 (scripts/), never by the product"
         )
     _lib = lib
     return lib

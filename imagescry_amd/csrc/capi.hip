@@ -9,6 +9,14 @@
 
 extern "C" int isc_abi_version(void) { return ISC_ABI_VERSION; }
 
+extern "C" int isc_build_flags(void) {
+#ifdef ISC_ABLATION
+    return ISC_BUILD_ABLATION;
+#else
+    return 0;
+#endif
+}
+
 extern "C" const char* isc_strerror(int status) {
     switch (status) {
         case ISC_OK: return "ok";

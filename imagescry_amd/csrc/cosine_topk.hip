@@ -64,7 +64,7 @@ constexpr int TARGET_WGS = 256;  // one workgroup per MI355X CU (the kernel uses
 constexpr int QCAP = 8192;  // candidates per query per level that the compact list / the selection can hold
 constexpr int SLACK = 6;
 constexpr int SMALL_Q = 128;  // up to this many queries the 64-query tile shape is used
-constexpr int QBATCH = 1024;  // queries per pass: larger calls run as several passes over the same workspace
+constexpr int QBATCH = ISC_SEARCH_PASS_QUERIES;  // queries per pass: larger calls run as several passes over the same workspace
 constexpr int MAX_LEVELS = 12;
 constexpr int SEL_THREADS = 512;
 constexpr int SURV_CAP = 2048;  // candidates the selection's exact ranking step accepts
@@ -1179,6 +1179,12 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void k_final(
     // which the matrix core adds its 32 products
     const double bmax = norm_bound ? (double)*norm_bound : 1.001;
     const double eps = (double)(ks * (ISC_KSTEP_BYTES / (int)sizeof(T))) * (1.0 / 8388608.0) * qnorm * bmax;
+    // The bound is RELATIVE: it assumes every product and partial sum stays in float32's normal range (round to nearest at
+    // every accumulation step of the matrix core is assumed too; status[2] < 1 is what the tests assert about it).  A query
+    // of denormal scale loses product bits to underflow, one of huge scale can overflow a partial sum to inf / NaN while
+    // the float64 score is finite -- and such rows are dropped silently by the filter.  |partial sum| <= ||q|| max||b||, so
+    // outside [1e-30, 1e37] (and for a NaN / inf norm) the query is answered by the exact pass instead.
+    if (!(qnorm >= 1e-30) || !(qnorm * bmax <= 1e37)) redo = true;
     if (tid < nc) {
         const unsigned long long mykey = isc_make_key(fsc[tid], orig[tid]);
         int rank = 0;

@@ -897,16 +897,7 @@ static bool conv_no_dma() {
 static constexpr bool conv_no_dma() { return false; }
 #endif
 
-static int conv_cu_count() {
-    static const int n = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        return cus;
-    }();
-    return n;
-}
+static int conv_cu_count() { return isc_device_cus(); }  // of the current device, cached per device id
 #ifdef ISC_ABLATION
 static bool conv_one_tile_per_wg() {
     static const bool v = getenv("ISC_CONV_NO_PERSIST") != nullptr;  // A/B aid: one workgroup per tile, as before

@@ -19,6 +19,22 @@ static inline hipStream_t isc_stream(void* s) { return reinterpret_cast<hipStrea
 
 static inline bool isc_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// Compute units of the CURRENT device, cached per device id (a process may drive several GPUs; thread-safe: the slots
+// are written with the same value by whoever gets there first).  256 when the query fails.
+static inline int isc_device_cus() {
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < 64) {
+        const int c = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+        if (c > 0) return c;
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (dev >= 0 && dev < 64) __atomic_store_n(&cached[dev], cus, __ATOMIC_RELAXED);
+    return cus;
+}
+
 // device-time bracket around one kernel launch (no-ops unless isc_timing_enable(1); defined in capi.hip)
 void isc_timing_begin(int kernel_id, hipStream_t stream);
 void isc_timing_end(int kernel_id, hipStream_t stream);

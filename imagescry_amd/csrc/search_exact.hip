@@ -292,31 +292,40 @@ int ex_check(int dtype, int64_t n, int d, int q, int k) {
 }
 
 template <typename T, int GQ>
-void launch_exact(const void* bank, int64_t n, int d, const void* queries, int64_t ldq, int k, int64_t index_base,
+int launch_exact(const void* bank, int64_t n, int d, const void* queries, int64_t ldq, int k, int64_t index_base,
                   const IscExactWs& ws, float* out_s, int64_t* out_i, int32_t* status, hipStream_t stream) {
     const int ks = isc_ksteps(d, (int)sizeof(T));
     const int dp = ks * (ISC_KSTEP_BYTES / (int)sizeof(T));
     const size_t lds = (size_t)GQ * dp * 8 + (size_t)GQ * EX_WAVES * k * 8;
     const int ntiles = (int)isc_ceil_div<int64_t>(n, ISC_TILE_ROWS);
-    static bool attr_set = false;  // more than 64 KiB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_exact<T, GQ>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
+    // more than 64 KiB of dynamic LDS needs the opt-in, once per kernel AND device (a process may drive several GPUs):
+    // one bit per device id, set only after the call succeeded; a failure is reported, not discarded
+    static unsigned long long attr_done = 0ull;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return ISC_ERR_NO_DEVICE;
+    const bool tracked = dev >= 0 && dev < 64;
+    if (!tracked || !((__atomic_load_n(&attr_done, __ATOMIC_RELAXED) >> dev) & 1ull)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_exact<T, GQ>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return ISC_ERR_UNSUPPORTED;
+        }
+        if (tracked) __atomic_fetch_or(&attr_done, 1ull << dev, __ATOMIC_RELAXED);
     }
     hipLaunchKernelGGL((k_exact<T, GQ>), dim3(ws.chunks), dim3(EX_THREADS), lds, stream,
                        static_cast<const unsigned char*>(bank), ks, isc_make_perm(n), ntiles, ws.tiles_per_chunk,
                        static_cast<const T*>(queries), ldq, d, k, index_base, ws.redo_count, ws.redo_list, ws.part,
                        ws.done, out_s, out_i, status);
+    return ISC_OK;
 }
 
 template <typename T>
-void launch_exact_t(const void* bank, int64_t n, int d, const void* queries, int64_t ldq, int k, int64_t index_base,
+int launch_exact_t(const void* bank, int64_t n, int d, const void* queries, int64_t ldq, int k, int64_t index_base,
                     const IscExactWs& ws, float* out_s, int64_t* out_i, int32_t* status, hipStream_t stream) {
     const int dp = isc_ksteps(d, (int)sizeof(T)) * (ISC_KSTEP_BYTES / (int)sizeof(T));
-    if (dp <= 3072) launch_exact<T, 4>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream);
-    else if (dp <= 6144) launch_exact<T, 2>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream);
-    else launch_exact<T, 1>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream);
+    if (dp <= 3072) return launch_exact<T, 4>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream);
+    if (dp <= 6144) return launch_exact<T, 2>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream);
+    return launch_exact<T, 1>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream);
 }
 
 }  // namespace
@@ -342,11 +351,10 @@ IscExactWs isc_exact_ws_carve(void* base, int64_t n, int q, int k) {
 int isc_exact_launch(int dtype, const void* bank, int64_t n, int d, const void* queries, int64_t ldq, int k,
                      int64_t index_base, const IscExactWs& ws, float* out_s, int64_t* out_i, int32_t* status,
                      hipStream_t stream) {
-    if (dtype == ISC_F16)
-        launch_exact_t<_Float16>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream);
-    else
-        launch_exact_t<float>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream);
-    return isc_launch_status();
+    const int st = dtype == ISC_F16
+                       ? launch_exact_t<_Float16>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream)
+                       : launch_exact_t<float>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream);
+    return st != ISC_OK ? st : isc_launch_status();
 }
 
 extern "C" int isc_topk_merge(const float* scores, const int64_t* indices, int G, int Q, int kin, int kout,

@@ -94,7 +94,7 @@ class EmbeddingModule(ABC):
         """preprocess -> forward -> L2-normalise each embedding vector (reference: embedding.py:57-76)."""
         if not isinstance(batch, ImageBatch):
             raise TypeError(f"batch must be an ImageBatch, got {type(batch).__name__}")
-        if type(self)._forward_nhwc4 is not EmbeddingModule._forward_nhwc4:
+        if self._fused_predict_ok():
             # preprocess and forward back to back: the normalisation writes the stem's channels-last layout directly
             # (same values as `forward(preprocess(images))`, one pass less over the batch)
             x = self._forward_nhwc4(self.preprocess(batch.images, _nhwc4=True))
@@ -106,6 +106,17 @@ class EmbeddingModule(ABC):
     def _forward_nhwc4(self, x4: Tensor) -> Tensor:
         """`forward` from the stem's own input layout `[B, H, W, 4]` (RGB + a zero channel); optional."""
         raise NotImplementedError
+
+    def _fused_predict_ok(self) -> bool:
+        """The fused preprocess -> forward path is taken only when `forward`, `preprocess` and `_forward_nhwc4` are
+        all the library class's own: a user subclass that overrides `forward` or `preprocess` (the two methods the
+        reference's subclasses implement, embedding.py:42-55) gets exactly `forward(preprocess(images))`."""
+        cls = type(self)
+        owner = next((c for c in cls.__mro__ if "_forward_nhwc4" in c.__dict__), EmbeddingModule)
+        if owner is EmbeddingModule:
+            return False
+        return (cls.forward is owner.forward and cls.preprocess is owner.preprocess
+                and cls._forward_nhwc4 is owner._forward_nhwc4)
 
     def embed_images(
         self,
@@ -133,6 +144,16 @@ class EmbeddingModule(ABC):
         for batch in dataloader:
             results.append(self.predict_step(batch.to(self.device)))
         return results
+
+
+# The convolution kernels index activations with 32-bit ELEMENT offsets: a pass holds at most this many elements in
+# its largest activation (tests lower it to take the multi-pass branch at small sizes).
+MAX_ACTIVATION_ELEMENTS = 2**31 - 1
+
+
+def images_per_pass(batch: int, per_image_elements: int) -> int:
+    """Images one pass of an encoder may hold so that `per_image_elements` x images stays addressable."""
+    return max(1, min(batch, MAX_ACTIVATION_ELEMENTS // max(per_image_elements, 1)))
 
 
 def lib_nchw_to_nhwc(x: Tensor, x4: Tensor) -> int:
@@ -227,9 +248,9 @@ class ResNet50Embedder(EmbeddingModule):
             raise ValueError(f"module is on {self.device} but the input is on {x4.device}; call .to() first")
         b, h, w, _ = x4.shape
         ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
-        # the kernels index with 32-bit element offsets: bound the images per pass
-        per_image = max(ho * wo * 256, 1)
-        chunk = max(1, min(b, (2**31 - 1) // per_image))
+        # the kernels index with 32-bit element offsets: bound the images per pass (64 ho wo elements in the stem
+        # output and in layer1's 256-channel output at half the resolution; 4x margin)
+        chunk = images_per_pass(b, ho * wo * 256)
         out = torch.empty((b, self._embedding_dim), dtype=torch.float32, device=x4.device)
         with torch.cuda.device(x4.device):
             for b0 in range(0, b, chunk):
@@ -341,8 +362,7 @@ class EfficientNetEmbedder(EmbeddingModule):
             raise ValueError(f"module is on {self.device} but the input is on {x4.device}; call .to() first")
         b, h, w, _ = x4.shape
         ho, wo = (h + 1) // 2, (w + 1) // 2
-        per_image = max(ho * wo * 256, 1)  # largest activation of one image, in elements (32-bit kernel offsets)
-        chunk = max(1, min(b, (2**31 - 1) // per_image))
+        chunk = images_per_pass(b, ho * wo * 256)  # largest activation of one image (32-bit kernel offsets), 4x margin
         outs = []
         with torch.cuda.device(x4.device):
             for b0 in range(0, b, chunk):

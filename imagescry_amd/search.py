@@ -20,7 +20,10 @@ cells of one image adjacent, operations.py:135-144 -- behave like shuffled ones;
 Multi-GPU: one process per GPU.  The bank is row-sharded -- rank r holds rows `[r*N//G, (r+1)*N//G)` -- every
 rank searches its shard with the replicated queries, one all-gather (RCCL over xGMI) exchanges the
 `Q x k x 12 B` partial results and every rank merges them; the merge order is total, so the answer does not
-depend on G.
+depend on G.  The exchange is software-pipelined: the local search runs on the caller's stream, the all-gather and
+the merge on the bank's own exchange stream (ordered by events, two exchange buffers), and `search_async` returns as
+soon as the merge is enqueued -- in a stream of searches the exchange of search i runs under the local kernels of
+search i + 1.
 """
 
 from __future__ import annotations
@@ -36,7 +39,7 @@ from torch import Tensor
 from imagescry_amd import _lib
 from imagescry_amd.data import EmbeddingBatch
 
-__all__ = ["EmbeddingBank", "shard_bounds"]
+__all__ = ["EmbeddingBank", "SearchHandle", "shard_bounds"]
 
 _PAD_INDEX = torch.iinfo(torch.int64).max
 
@@ -46,6 +49,42 @@ def shard_bounds(n_rows: int, world_size: int, rank: int) -> tuple[int, int]:
     if world_size <= 0 or not 0 <= rank < world_size:
         raise ValueError(f"invalid rank {rank} for world size {world_size}")
     return rank * n_rows // world_size, (rank + 1) * n_rows // world_size
+
+
+class SearchHandle:
+    """Result of `EmbeddingBank.search_async`.  The tensors exist at once; their CONTENTS are final when the event
+    recorded behind the merge has fired.  `result()` orders the caller's current stream behind that event (no host
+    synchronisation) and returns `(scores, indices)`."""
+
+    __slots__ = ("_scores", "_indices", "_event", "_keep", "gathered_status")
+
+    def __init__(self, scores: Tensor, indices: Tensor, event: "torch.cuda.Event | None" = None,
+                 keep: Tensor | None = None, gathered_status: Tensor | None = None) -> None:
+        self._scores = scores
+        self._indices = indices
+        self._event = event
+        self._keep = keep  # the gathered exchange buffers (`gathered_status` is a view into them)
+        self.gathered_status = gathered_status
+
+    def result(self) -> tuple[Tensor, Tensor]:
+        if self._event is not None:
+            cur = torch.cuda.current_stream(self._scores.device)
+            cur.wait_event(self._event)
+            for t in (self._scores, self._indices, self._keep):  # allocated on the exchange stream, used on this one
+                if t is not None:
+                    t.record_stream(cur)
+            self._event = None
+        return self._scores, self._indices
+
+
+class _ExchangeSlot:
+    """One of the two exchange buffers of a sharded bank and the event behind the last exchange that read it."""
+
+    __slots__ = ("buf", "done")
+
+    def __init__(self) -> None:
+        self.buf: Tensor | None = None
+        self.done: "torch.cuda.Event | None" = None
 
 
 class EmbeddingBank:
@@ -96,7 +135,11 @@ class EmbeddingBank:
             raise ValueError("embedding dimension must be positive")
         self._bank = self._store(embeddings, normalize)
         self._workspaces: dict[tuple[int, int], Tensor] = {}
+        self._slots = (_ExchangeSlot(), _ExchangeSlot())
+        self._slot_next = 0
+        self._xstream: "torch.cuda.Stream | None" = None
         self.last_status: Tensor | None = None
+        self.last_gathered_status: Tensor | None = None
         self.row_origin: Tensor | None = None  # set by from_database: (image_id, h, w) of every row
 
     # ------------------------------------------------------------------ construction
@@ -199,17 +242,24 @@ class EmbeddingBank:
         return queries.to(self.dtype).contiguous()
 
     def _workspace(self, n_queries: int, k: int) -> Tensor:
-        key = (n_queries, k)
+        """The search workspace.  The C side runs a call as passes of at most `ISC_SEARCH_PASS_QUERIES` queries over
+        one workspace and cuts the queries into tiles of 64 (up to 128 queries) or 256, so the size depends on
+        (padded queries of a pass, k) only: alternating batch sizes inside one bucket -- a pipeline's short last
+        batch -- reuse one allocation instead of reallocating 150-300 MB per call.  One buffer per bucket is kept."""
+        nq = min(n_queries, _lib.ISC_SEARCH_PASS_QUERIES)
+        key = (-(-nq // 64) * 64 if nq <= 128 else -(-nq // 256) * 256, k)
         ws = self._workspaces.get(key)
         if ws is None:
             lib = _lib.load()
             need = _lib.c_size_t()
             st = lib.isc_cosine_topk_workspace_bytes(
-                _lib.dtype_code(self.dtype), self.num_local_rows, self.dim, n_queries, k, need
+                _lib.dtype_code(self.dtype), self.num_local_rows, self.dim, min(key[0], _lib.ISC_SEARCH_PASS_QUERIES), k, need
             )
             _lib.check(st, "isc_cosine_topk_workspace_bytes")
             ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
-            self._workspaces = {key: ws}  # keep one: the workspace can be > 100 MiB
+            if len(self._workspaces) >= 4:  # bound what a bank pins: drop the oldest bucket
+                self._workspaces.pop(next(iter(self._workspaces)))
+            self._workspaces[key] = ws
         return ws
 
     def _local_topk(
@@ -296,9 +346,18 @@ class EmbeddingBank:
         only enqueues work: no host synchronisation, and the result is final -- queries the float32 filter cannot
         prove are redone exactly on the device.  `last_status` (int32[4], device) holds diagnostics: [0] overflowed
         candidate buffers, [1] queries answered by the exact pass.  `check` is accepted for compatibility with the
-        first version of this API and ignored.
+        first version of this API and ignored.  Equivalent to `search_async(queries, k).result()`.
         """
         del check
+        return self.search_async(queries, k).result()
+
+    def search_async(self, queries: Tensor, k: int = 10) -> SearchHandle:
+        """`search` that returns as soon as everything is ENQUEUED; `handle.result()` orders the caller's current stream
+        behind the answer.  For a sharded bank the local kernels run on the caller's stream and the exchange
+        (all-gather + merge) on the bank's exchange stream, so a caller that issues search i + 1 before it resolves
+        handle i has exchange i running under the local kernels of i + 1.  Two exchange buffers alternate: at most two
+        searches of one bank should be unresolved at a time (a third waits, on the device, for the first one's
+        exchange)."""
         if not isinstance(k, int) or isinstance(k, bool):
             raise TypeError(f"k must be an int, got {type(k).__name__}")
         if k < 1:
@@ -311,9 +370,9 @@ class EmbeddingBank:
             if k > self.num_local_rows:
                 raise ValueError(f"k={k} exceeds the bank size {self.num_local_rows}")
             if nq == 0:
-                return (torch.empty((0, k), dtype=torch.float32, device=self.device),
-                        torch.empty((0, k), dtype=torch.int64, device=self.device))
-            return self._local_topk(q, k)
+                return SearchHandle(torch.empty((0, k), dtype=torch.float32, device=self.device),
+                                    torch.empty((0, k), dtype=torch.int64, device=self.device))
+            return SearchHandle(*self._local_topk(q, k))
 
         # ---- sharded: local partial top-k -> ONE all-gather -> merge on every rank.  Every rank issues exactly one
         # collective per search whatever its shard holds, so the ranks cannot fall out of step.
@@ -322,14 +381,23 @@ class EmbeddingBank:
         if k > self._n_total:
             raise ValueError(f"k={k} exceeds the bank size {self._n_total}")
         if nq == 0:
-            return (torch.empty((0, k), dtype=torch.float32, device=self.device),
-                    torch.empty((0, k), dtype=torch.int64, device=self.device))
+            return SearchHandle(torch.empty((0, k), dtype=torch.float32, device=self.device),
+                                torch.empty((0, k), dtype=torch.int64, device=self.device))
         # exchange buffer of this rank: [scores f32 Q*k | indices i64 Q*k | status i32 x4], written in place by the
         # search kernels, gathered with ONE collective and read in place by the merge kernel
         off_i = (4 * nq * k + 7) // 8 * 8
         off_s = off_i + 8 * nq * k
         nbytes = off_s + 16
-        xbuf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        on_gpu = self.device.type == "cuda"
+        slot = self._slots[self._slot_next]
+        self._slot_next ^= 1
+        if on_gpu:
+            cur = torch.cuda.current_stream(self.device)
+            if slot.done is not None:  # the exchange that last read this buffer (two searches ago)
+                cur.wait_event(slot.done)
+        if slot.buf is None or slot.buf.numel() < nbytes:
+            slot.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        xbuf = slot.buf[:nbytes]
         part_s = xbuf[: 4 * nq * k].view(torch.float32).view(nq, k)
         part_i = xbuf[off_i:off_s].view(torch.int64).view(nq, k)
         status = xbuf[off_s:].view(torch.int32)
@@ -343,16 +411,31 @@ class EmbeddingBank:
                 part_s[:, :kl] = s
                 part_i[:, :kl] = i
         else:
-            s, i = self._local_topk(q, k, out=(part_s, part_i, status))
-            if s.data_ptr() != part_s.data_ptr():  # a test double returned its own tensors
-                part_s.copy_(s)
-                part_i.copy_(i)
-                status.zero_()
-        gathered = self._all_gather_bytes(xbuf)
-        all_s = gathered[:, : 4 * nq * k].view(torch.float32).view(self.world_size, nq, k)
-        all_i = gathered[:, off_i:off_s].view(torch.int64).view(self.world_size, nq, k)
-        self.last_gathered_status = gathered[:, off_s:].view(torch.int32)  # [G, 4]: every shard's diagnostics
-        return self._merge_topk(all_s, all_i, k)
+            self._local_topk(q, k, out=(part_s, part_i, status))
+
+        def exchange() -> tuple[Tensor, Tensor, Tensor, Tensor]:
+            gathered = self._all_gather_bytes(xbuf)
+            all_s = gathered[:, : 4 * nq * k].view(torch.float32).view(self.world_size, nq, k)
+            all_i = gathered[:, off_i:off_s].view(torch.int64).view(self.world_size, nq, k)
+            out_s, out_i = self._merge_topk(all_s, all_i, k)
+            return out_s, out_i, gathered, gathered[:, off_s:].view(torch.int32)  # [G, 4]: every shard's diagnostics
+
+        if not on_gpu:  # CPU tensors (the gloo rehearsal of the host logic): nothing to overlap
+            out_s, out_i, gathered, gstatus = exchange()
+            self.last_gathered_status = gstatus
+            return SearchHandle(out_s, out_i, None, gathered, gstatus)
+        if self._xstream is None:
+            self._xstream = torch.cuda.Stream(self.device)
+        local_done = torch.cuda.Event()
+        local_done.record(cur)
+        with torch.cuda.stream(self._xstream):
+            self._xstream.wait_event(local_done)
+            out_s, out_i, gathered, gstatus = exchange()
+            done = torch.cuda.Event()
+            done.record(self._xstream)
+        slot.done = done
+        self.last_gathered_status = gstatus  # valid once the handle has been resolved
+        return SearchHandle(out_s, out_i, done, gathered, gstatus)
 
     def _all_gather_bytes(self, xbuf: Tensor) -> Tensor:
         """`[G, nbytes]` uint8: every rank's exchange buffer (one all-gather; RCCL over xGMI on the GPUs)."""

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ISC_ABI_VERSION 2
+#define ISC_ABI_VERSION 3
 
 /* element types */
 #define ISC_U8 0
@@ -54,6 +54,11 @@ extern "C" {
 #define ISC_ACT_RESIDUAL_AFTER 0x100 /* OR into `act`: out = act(conv + bias) + residual (default: residual inside act) */
 
 int isc_abi_version(void);
+/* how the library was built: bit 0 (ISC_BUILD_ABLATION) = compiled with -DISC_ABLATION, i.e. it contains the timing
+ * variants of the kernels that return WRONG results by design and reads ISC_DEBUG_MODE-style environment variables.  The
+ * production library returns 0; a binding must refuse a library with bit 0 set unless ablation runs were asked for. */
+#define ISC_BUILD_ABLATION 1
+int isc_build_flags(void);
 const char* isc_strerror(int status);
 /* device properties the host side sizes launches with; any out pointer may be NULL (host pointers) */
 int isc_device_info(int* num_cus, int* lds_bytes_per_cu, char* arch_name, int arch_name_len);
@@ -279,6 +284,7 @@ int isc_vit_assemble(const float* patch_embed, const float* cls_token, const flo
 #define ISC_TOPK_MAX_K 120
 #define ISC_SEARCH_MAX_D 8192
 #define ISC_SEARCH_MAX_Q (1 << 24)
+#define ISC_SEARCH_PASS_QUERIES 1024 /* queries per pass; the workspace size depends on min(Q, this) rounded up to a query tile */
 int isc_cosine_topk_workspace_bytes(int dtype, int64_t N, int D, int Q, int k, size_t* bytes);
 int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, const void* queries, int Q, int64_t ldq, int k,
                     int64_t index_base, const float* norm_bound, float* out_scores, int64_t* out_indices,

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-export ISC_LIB=$GRAFT_REPO_ROOT/imagescry_amd/libimagescry_hip_ablation.so
+export ISC_LIB=$GRAFT_REPO_ROOT/imagescry_amd/libimagescry_hip_ablation.so ISC_ALLOW_ABLATION=1
 export ISC_GEMM_PHASES=0
 for dbg in 0 5 1; do
   echo "== ISC_GEMM_DEBUG=$dbg"; ISC_GEMM_DEBUG=$dbg python3 scripts/quick_gemm_bench.py 2>&1 | grep -v amdgpu.ids | grep "qkv\|fc1"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # where the level-0 ("sample") kernel spends its time: kernel trace of the ablation build with the epilogue / tail cut off
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-export ISC_LIB=$GRAFT_REPO_ROOT/imagescry_amd/libimagescry_hip_ablation.so
+export ISC_LIB=$GRAFT_REPO_ROOT/imagescry_amd/libimagescry_hip_ablation.so ISC_ALLOW_ABLATION=1
 for abl in 0 1 2; do
   rm -rf gpurun_out/prof_abl
   ISC_SAMPLE_ABL=$abl rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_abl -- python3 scripts/quick_search_bench.py "$@" > gpurun_out/prof_abl.log 2>&1

@@ -44,7 +44,8 @@ def test_host_only_entry_points(library: ctypes.CDLL) -> None:
     """Functions that touch no device memory can run here: version, error strings, workspace sizing,
     argument validation."""
     lib = _lib.load()
-    assert lib.isc_abi_version() == _lib.ISC_ABI_VERSION == 2
+    assert lib.isc_abi_version() == _lib.ISC_ABI_VERSION == 3
+    assert lib.isc_build_flags() == 0  # the production build: no ablation variants
     assert _lib.strerror(0) == "ok"
     assert "workspace" in _lib.strerror(_lib.ISC_ERR_WORKSPACE)
     need = ctypes.c_size_t()

@@ -42,9 +42,12 @@ def _worker(rank: int, world: int, port: int, n: int, k: int, out_dir: str) -> N
             def _store(self, embeddings, normalize):  # keep the rows on the CPU
                 return embeddings.contiguous()
 
-            def _local_topk(self, queries, kk, out=None):  # `out`: the product's exchange buffer (unused here)
+            def _local_topk(self, queries, kk, out=None):  # `out`: the product's exchange buffer, filled in place
                 s, i = search_oracle.cosine_topk(self._bank, queries, kk, index_base=self.index_base)
-                return torch.from_numpy(s), torch.from_numpy(i)
+                s, i = torch.from_numpy(s), torch.from_numpy(i)
+                if out is not None:
+                    out[0].copy_(s), out[1].copy_(i), out[2].zero_()
+                return s, i
 
             def _merge_topk(self, scores, indices, kk):
                 s, i = search_oracle.topk_merge(scores.numpy(), indices.numpy(), kk)
@@ -100,9 +103,12 @@ def _uneven_worker(rank: int, world: int, port: int, k: int, out_dir: str) -> No
             def _store(self, embeddings, normalize):
                 return embeddings.contiguous()
 
-            def _local_topk(self, queries, kk, out=None):
+            def _local_topk(self, queries, kk, out=None):  # `out`: the product's exchange buffer, filled in place
                 s, i = search_oracle.cosine_topk(self._bank, queries, kk, index_base=self.index_base)
-                return torch.from_numpy(s), torch.from_numpy(i)
+                s, i = torch.from_numpy(s), torch.from_numpy(i)
+                if out is not None:
+                    out[0].copy_(s), out[1].copy_(i), out[2].zero_()
+                return s, i
 
             def _merge_topk(self, scores, indices, kk):
                 s, i = search_oracle.topk_merge(scores.numpy(), indices.numpy(), kk)
@@ -122,6 +128,12 @@ def _uneven_worker(rank: int, world: int, port: int, k: int, out_dir: str) -> No
         for _ in range(2):
             scores, indices = eb.search(queries, k)
         assert calls["gather"] == 2  # one collective per search on every rank
+        handles = [eb.search_async(queries, k) for _ in range(3)]  # the pipelined form: still one collective each
+        assert calls["gather"] == 5
+        for h in handles:
+            s2, i2 = h.result()
+            assert torch.equal(s2, scores) and torch.equal(i2, indices)
+            assert h.gathered_status.shape == (world, 4)
         exp_s, exp_i = search_oracle.cosine_topk(bank, queries, k)
         np.testing.assert_array_equal(indices.numpy(), exp_i)
         np.testing.assert_array_equal(scores.numpy(), exp_s)
@@ -149,9 +161,12 @@ def _pipeline_worker(rank: int, world: int, port: int, n: int, k: int, out_dir: 
             def _store(self, embeddings, normalize):
                 return embeddings.contiguous()
 
-            def _local_topk(self, queries, kk, out=None):
+            def _local_topk(self, queries, kk, out=None):  # `out`: the product's exchange buffer, filled in place
                 s, i = search_oracle.cosine_topk(self._bank, queries, kk, index_base=self.index_base)
-                return torch.from_numpy(s), torch.from_numpy(i)
+                s, i = torch.from_numpy(s), torch.from_numpy(i)
+                if out is not None:
+                    out[0].copy_(s), out[1].copy_(i), out[2].zero_()
+                return s, i
 
             def _merge_topk(self, scores, indices, kk):
                 s, i = search_oracle.topk_merge(scores.numpy(), indices.numpy(), kk)

@@ -555,3 +555,26 @@ def test_large_k_on_a_multi_level_bank(k: int, dtype: torch.dtype, device: torch
     s2, i2 = eb.search(queries[keep].to(device), k)
     assert eb.last_status.cpu().tolist()[0] == 0  # without the degenerate query no candidate buffer overflows
     assert torch.equal(i2, indices[keep]) and torch.equal(s2, scores[keep])
+
+
+def test_denormal_and_huge_scale_float32_queries(device: torch.device) -> None:
+    """The rounding guard's bound is relative: it holds while products and partial sums stay in float32's normal range.
+    A float32 query scaled to 1e-40 (products underflow, the filter scores lose their bits) or to 1e37 (a partial sum
+    can overflow while the float64 score is finite) must therefore be answered by the exact pass -- `k_final` lists them
+    -- and rank exactly as the oracle ranks them (the reference normalises the query first and is unaffected by scale)."""
+    bank, queries = cases.search_case(5000, 64, 4, torch.float32, seed=77)
+    queries = queries.clone()
+    queries[0] *= 1e-40
+    queries[1] *= 1e37
+    eb = _bank(bank, device)
+    scores, indices = eb.search(queries.to(device), 10)
+    exp_s, exp_i = search_oracle.cosine_topk(bank, queries, 10)
+    np.testing.assert_array_equal(indices.cpu().numpy(), exp_i)
+    np.testing.assert_allclose(scores.cpu().numpy(), exp_s, rtol=1e-6, atol=0)
+    st = eb.last_status.cpu().tolist()
+    assert st[1] >= 2, st  # both extreme queries went through the exact pass
+    # the same directions at unit scale rank identically (cosine is scale free) and stay on the fast path
+    unit = torch.nn.functional.normalize(queries.double(), dim=1).float()
+    s1, i1 = eb.search(unit.to(device), 10)
+    assert int(eb.last_status.cpu()[1]) == 0
+    assert torch.equal(i1[2:], indices[2:])
