@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256) void k_bank_pack(const TIN* __restrict__ x, in
         stored_sq = isc_wave_sum(stored_sq);
         // float32 summation of d squares: relative error <= d * 2^-24 -- cover it (and the sqrt) with a factor
         const float nb = sqrtf(stored_sq) * (1.f + 1e-3f);
-        if (lane == 0 && nb == nb) atomicMax(norm_bound, __float_as_uint(nb));  // non-negative floats order as uints
+        // non-negative floats order as uints; a row holding NaN makes the bound +inf: the search then trusts no filter
+        // result on this bank and answers through its exhaustive pass
+        if (lane == 0) atomicMax(norm_bound, nb == nb ? __float_as_uint(nb) : 0x7f800000u);
     }
 }
 

@@ -178,6 +178,9 @@ Plan make_plan(int64_t n, int q, int k) {
         add(seen, r1, 0);
         seen = r1;
     }
+    // the redo of unproven queries streams the WHOLE bank as one level (run()): its chunks need segments too
+    const int redo_chunks = (int)(wgs < ntiles_all ? wgs : ntiles_all);
+    if (p.segs_per_chunk * redo_chunks > p.max_seg) p.max_seg = p.segs_per_chunk * redo_chunks;
     return p;
 }
 
@@ -191,7 +194,14 @@ struct Workspace {
     int32_t* qcount;         // [qpad]                survivors per query of the current level
     Cand* qlist;             // [qpad][QCAP]          ... compacted at the end of k_dots_filter
     unsigned char* qpacked;  // [qtiles][ks][tnq][128 B]
-    IscExactWs exact;        // redo list + partial lists of k_exact
+    // matrix-core redo of the queries whose first answer k_final cannot prove (see k_final / k_final2)
+    int32_t* r_count;         // [1]     listed queries ("slots")
+    int32_t* r_list;          // [qpad]  slot -> query of this pass
+    float* tau2;              // [qpad]  slot -> fixed threshold of the redo filter (+inf: unused slot)
+    int32_t* qcount2;         // [qpad]  slot -> survivors of the redo filter
+    int32_t* qflag2;          // [qpad]  slot -> a candidate buffer overflowed
+    unsigned char* qpacked2;  // [qtiles][ks][tnq][128 B]  packed query rows by slot
+    IscExactWs exact;        // list + partial lists of k_exact (the exhaustive float64 pass, the last resort)
     size_t bytes;
 };
 
@@ -212,6 +222,12 @@ Workspace carve(const Plan& p, int ks, int64_t n, int k, void* base) {
     w.qcount = static_cast<int32_t*>(take((size_t)p.qpad * 4));
     w.qlist = static_cast<Cand*>(take((size_t)p.qpad * QCAP * sizeof(Cand)));
     w.qpacked = static_cast<unsigned char*>(take((size_t)p.qpad * ks * ISC_KSTEP_BYTES));
+    w.r_count = static_cast<int32_t*>(take(4));
+    w.r_list = static_cast<int32_t*>(take((size_t)p.qpad * 4));
+    w.tau2 = static_cast<float*>(take((size_t)p.qpad * 4));
+    w.qcount2 = static_cast<int32_t*>(take((size_t)p.qpad * 4));
+    w.qflag2 = static_cast<int32_t*>(take((size_t)p.qpad * 4));
+    w.qpacked2 = static_cast<unsigned char*>(take((size_t)p.qpad * ks * ISC_KSTEP_BYTES));
     const size_t ex = isc_exact_ws_bytes(n, p.qb, k);
     w.exact = isc_exact_ws_carve(take(ex), n, p.qb, k);
     w.bytes = off;
@@ -226,7 +242,9 @@ __global__ __launch_bounds__(256) void k_prep(const T* __restrict__ queries, int
                                               int tnq, unsigned char* __restrict__ packed, float* __restrict__ tau,
                                               int32_t* __restrict__ carry_n, int32_t* __restrict__ qcount,
                                               int32_t* __restrict__ qflag, int32_t* __restrict__ redo_count,
-                                              int32_t* __restrict__ exact_done, int32_t* __restrict__ status,
+                                              int32_t* __restrict__ exact_done, int32_t* __restrict__ r_count,
+                                              float* __restrict__ tau2, int32_t* __restrict__ qcount2,
+                                              int32_t* __restrict__ qflag2, int32_t* __restrict__ status,
                                               int zero_status) {
     constexpr int PER = 16 / (int)sizeof(T);
     const int total = qpad * ks * 8;
@@ -236,10 +254,14 @@ __global__ __launch_bounds__(256) void k_prep(const T* __restrict__ queries, int
         carry_n[i] = 0;
         qcount[i] = 0;
         qflag[i] = 0;
+        tau2[i] = INFINITY;  // redo slots: unused ones never pass the redo filter
+        qcount2[i] = 0;
+        qflag2[i] = 0;
     }
     if (i == 0) {
         *redo_count = 0;
         *exact_done = 0;
+        *r_count = 0;
     }
     if (zero_status && i < 4) status[i] = 0;
     if (i >= total) return;
@@ -350,7 +372,10 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                                                           const float* __restrict__ tau, int qpad,
                                                           Cand* __restrict__ seg_ent, int32_t* __restrict__ qcount,
                                                           Cand* __restrict__ qlist, int kp, int nslots,
-                                                          int32_t* __restrict__ qflag, int32_t* __restrict__ status) {
+                                                          int32_t* __restrict__ qflag, int32_t* __restrict__ status,
+                                                          const int32_t* __restrict__ active) {
+    // redo launches (k_final2's feeder): `active` counts the listed query slots -- normally zero, and the launch ends here
+    if (active != nullptr && *active <= (int)blockIdx.y * TNQ) return;
     constexpr int WN = TNQ / 64;              // waves along the queries
     constexpr int WM = 8 / WN;                // waves along the bank rows
     constexpr int MB = TM / WM / 16;          // 16-row blocks per wave: 8 (TNQ 256) or 2 (TNQ 64)
@@ -935,6 +960,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 //   3. candidates >= lim (typically ~1.5 kp of them) are compacted into LDS;
 //   4. they are ranked exactly by counting larger keys.
 constexpr int SEL_PER = QCAP / SEL_THREADS;  // list entries per thread: the whole list sits in registers
+constexpr int SEL_SPEC_MANY = 4;             // speculative entries per thread when a call has more than SMALL_Q queries
 struct SelShared {
     unsigned long long surv[SURV_CAP];
     unsigned long long topk[ISC_TOPK_MAX_K + 8];
@@ -943,35 +969,13 @@ struct SelShared {
     int ns;
 };
 
-__device__ int wg_select(SelShared& sh, int q, int kp, const int32_t* __restrict__ qcount,
-                         const Cand* __restrict__ qlist, const float* __restrict__ carry_s,
-                         const int32_t* __restrict__ carry_r, const int32_t* __restrict__ carry_n) {
+// steps 1 (maxima) - 4 on keys that already sit in registers (0 = empty slot); the caller has set sh.ns = 0 before a
+// workgroup barrier or relies on the one inside step 2
+__device__ int wg_select_keys(SelShared& sh, const unsigned long long (&key)[SEL_PER + 1], int kp) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const Cand* src = qlist + (size_t)q * QCAP;
-    const int from_list = min(qcount[q], QCAP);
-    const int carried = min(carry_n[q], kp);
     if (tid == 0) sh.ns = 0;
-
-    // 1. every candidate into registers: SEL_PER independent coalesced 8-byte loads per thread, issued BEFORE the
-    // list length is known (the list buffer always holds QCAP slots; what lies past the length is ignored), so the
-    // counter and the list travel in one memory round trip; plus one carried entry (kp <= 128 < 512 threads)
-    unsigned long long key[SEL_PER + 1];
-    {
-        const unsigned long long* raw = reinterpret_cast<const unsigned long long*>(src);
-#pragma unroll
-        for (int j = 0; j < SEL_PER; ++j) key[j] = raw[tid + SEL_THREADS * j];
-        const int ci = min(tid, kp - 1);
-        const float cs = carry_s[(size_t)q * kp + ci];
-        const int cr = carry_r[(size_t)q * kp + ci];
-#pragma unroll
-        for (int j = 0; j < SEL_PER; ++j) {
-            const Cand e{__uint_as_float((unsigned)key[j]), (int)(unsigned)(key[j] >> 32)};
-            key[j] = tid + SEL_THREADS * j < from_list ? isc_make_key(e.s, e.row) : 0ull;
-        }
-        key[SEL_PER] = tid < carried ? isc_make_key(cs, cr) : 0ull;
-    }
     unsigned long long lmax = 0ull;
 #pragma unroll
     for (int j = 0; j <= SEL_PER; ++j) lmax = key[j] > lmax ? key[j] : lmax;
@@ -1033,14 +1037,58 @@ __device__ int wg_select(SelShared& sh, int q, int kp, const int32_t* __restrict
     return min(kp, ns);
 }
 
+// SPEC = list entries per thread that are loaded BEFORE the list length is known (the rest only if the list is that long).
+// With few queries (SPEC = SEL_PER) the whole 64 KiB buffer of a query is fetched blindly and counter and list travel in
+// one memory round trip; with a thousand queries that is 64 MB of list traffic per selection for lists that are
+// typically a quarter full, so only the first 2048 slots are speculative there and a longer list pays a second trip.
+template <int SPEC>
+__device__ int wg_select(SelShared& sh, int q, int kp, const int32_t* __restrict__ qcount,
+                         const Cand* __restrict__ qlist, const float* __restrict__ carry_s,
+                         const int32_t* __restrict__ carry_r, const int32_t* __restrict__ carry_n) {
+    const int tid = threadIdx.x;
+    const Cand* src = qlist + (size_t)q * QCAP;
+    const int from_list = min(qcount[q], QCAP);
+    const int carried = min(carry_n[q], kp);
+
+    // 1. every candidate into registers: SEL_PER independent coalesced 8-byte loads per thread, issued BEFORE the
+    // list length is known (the list buffer always holds QCAP slots; what lies past the length is ignored), so the
+    // counter and the list travel in one memory round trip; plus one carried entry (kp <= 128 < 512 threads)
+    unsigned long long key[SEL_PER + 1];
+    {
+        const unsigned long long* raw = reinterpret_cast<const unsigned long long*>(src);
+#pragma unroll
+        for (int j = 0; j < SPEC; ++j) key[j] = raw[tid + SEL_THREADS * j];
+        if constexpr (SPEC < SEL_PER) {
+            if (from_list > SPEC * SEL_THREADS) {  // workgroup-uniform
+#pragma unroll
+                for (int j = SPEC; j < SEL_PER; ++j) key[j] = raw[tid + SEL_THREADS * j];
+            } else {
+#pragma unroll
+                for (int j = SPEC; j < SEL_PER; ++j) key[j] = 0ull;
+            }
+        }
+        const int ci = min(tid, kp - 1);
+        const float cs = carry_s[(size_t)q * kp + ci];
+        const int cr = carry_r[(size_t)q * kp + ci];
+#pragma unroll
+        for (int j = 0; j < SEL_PER; ++j) {
+            const Cand e{__uint_as_float((unsigned)key[j]), (int)(unsigned)(key[j] >> 32)};
+            key[j] = tid + SEL_THREADS * j < from_list ? isc_make_key(e.s, e.row) : 0ull;
+        }
+        key[SEL_PER] = tid < carried ? isc_make_key(cs, cr) : 0ull;
+    }
+    return wg_select_keys(sh, key, kp);
+}
+
 // between two levels: carried list and tau of every query
+template <int SPEC>
 __global__ __launch_bounds__(SEL_THREADS, 4) void k_select(int32_t* __restrict__ qcount, const Cand* __restrict__ qlist,
                                                         int kp, float* __restrict__ tau, float* __restrict__ carry_s,
                                                         int32_t* __restrict__ carry_r, int32_t* __restrict__ carry_n,
                                                         int32_t* __restrict__ qflag) {
     __shared__ SelShared sh;
     const int q = blockIdx.x;
-    const int n = wg_select(sh, q, kp, qcount, qlist, carry_s, carry_r, carry_n);
+    const int n = wg_select<SPEC>(sh, q, kp, qcount, qlist, carry_s, carry_r, carry_n);
     const int tid = threadIdx.x;
     if (n < 0) {  // give up on the fast path for this query: nothing more survives, k_final lists it for k_exact
         if (tid == 0) {
@@ -1089,50 +1137,33 @@ struct Chunk16<float> {
     }
 };
 
-// One workgroup per query: last selection, exact float64 re-score of the carried candidates, final order, output,
-// and the guard that proves the float32 filter lost nothing (see the file header).
+// float64 norm of the packed query row at `qrow_base` (K step s at + s * tnq * 128 B); called by ONE wave, result in
+// every lane
 template <typename T>
-__global__ __launch_bounds__(SEL_THREADS, 4) void k_final(
-    const unsigned char* __restrict__ bank, int ks, const unsigned char* __restrict__ qpacked, int tnq, int kp, int k,
-    IscPerm pm, int64_t index_base, const float* __restrict__ norm_bound, const int32_t* __restrict__ qcount,
-    const Cand* __restrict__ qlist, const float* __restrict__ carry_s, const int32_t* __restrict__ carry_r,
-    const int32_t* __restrict__ carry_n, const int32_t* __restrict__ qflag, float* __restrict__ out_s,
-    int64_t* __restrict__ out_i, int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_list,
-    int32_t* __restrict__ status) {
-    __shared__ SelShared sh;
-    __shared__ double exact_dot[ISC_TOPK_MAX_K + 8];
-    __shared__ float fsc[ISC_TOPK_MAX_K + 8];
-    __shared__ int orig[ISC_TOPK_MAX_K + 8];
-    __shared__ double qnorm_sh;
-    __shared__ float kth_sh;
-    const int q = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int n = wg_select(sh, q, kp, qcount, qlist, carry_s, carry_r, carry_n);
-    bool redo = n < 0 || qflag[q] != 0;
-    const int nc = n < 0 ? 0 : n;
-
-    // this query's packed row: K step s at qrow_base + s * tnq * 128
-    const unsigned char* qrow_base = qpacked + ((size_t)(q / tnq) * ks * tnq + (q % tnq)) * ISC_KSTEP_BYTES;
-    const int sub = lane >> 3;  // K step within a group of 8
-    const int ch = lane & 7;    // 16-byte chunk of the K step
-    if (wave == 0) {
-        double acc = 0.0;
-        for (int s0 = 0; s0 < ks; s0 += 8) {
-            const int s = s0 + sub;
-            if (s < ks) {
-                double v[8];
-                Chunk16<T>::load(qrow_base + (size_t)s * tnq * ISC_KSTEP_BYTES + ch * 16, v);
+__device__ double wave_query_norm(const unsigned char* qrow_base, int ks, int tnq) {
+    const int lane = threadIdx.x & 63;
+    const int sub = lane >> 3, ch = lane & 7;
+    double acc = 0.0;
+    for (int s0 = 0; s0 < ks; s0 += 8) {
+        const int s = s0 + sub;
+        if (s < ks) {
+            double v[8];
+            Chunk16<T>::load(qrow_base + (size_t)s * tnq * ISC_KSTEP_BYTES + ch * 16, v);
 #pragma unroll
-                for (int j = 0; j < Chunk16<T>::N; ++j) acc = fma(v[j], v[j], acc);
-            }
+            for (int j = 0; j < Chunk16<T>::N; ++j) acc = fma(v[j], v[j], acc);
         }
-        acc = isc_wave_sum(acc);
-        if (lane == 0) qnorm_sh = sqrt(acc);
     }
-    // exact dots: one wave per candidate, a lane covers the 16-byte chunk `ch` of K steps sub, sub + 8, ...; four
-    // candidates of a wave are in flight together (their loads are independent)
+    return isc_wave_sum(acc);
+}
+
+// Exact float64 dots of `nc` candidates with one query: one wave per candidate, a lane covers the 16-byte chunk `ch` of
+// K steps sub, sub + 8, ...; four candidates of a wave are in flight together (their loads are independent).
+// row_of(c) -> packed row or -1; store(c, dot) is called by lane 0 of the wave that owns candidate c (dot = 0 for row -1).
+template <typename T, typename RowOf, typename Store>
+__device__ void exact_dots(const unsigned char* __restrict__ bank, int ks, const unsigned char* qrow_base, int tnq,
+                           int nc, int64_t nrows, RowOf row_of, Store store) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 3, ch = lane & 7;
     constexpr int NW = SEL_THREADS / 64;
     for (int c0 = wave; c0 < nc; c0 += 4 * NW) {
         int row[4];
@@ -1140,8 +1171,8 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void k_final(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = c0 + u * NW;
-            row[u] = c < nc ? isc_key_row(sh.topk[c]) : -1;
-            if ((unsigned)row[u] >= (unsigned)pm.n) row[u] = -1;
+            row[u] = c < nc ? row_of(c) : -1;
+            if ((unsigned)row[u] >= (unsigned)nrows) row[u] = -1;
             acc[u] = 0.0;
         }
         for (int s0 = 0; s0 < ks; s0 += 8) {
@@ -1161,30 +1192,88 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void k_final(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const double tot = isc_wave_sum(acc[u]);
-            if (lane == 0 && c0 + u * NW < nc) exact_dot[c0 + u * NW] = row[u] < 0 ? 0.0 : tot;
+            if (lane == 0 && c0 + u * NW < nc) store(c0 + u * NW, row[u] < 0 ? 0.0 : tot);
         }
     }
+}
+
+// What k_final does with a query it cannot prove.
+//   -> slot in the REDO list: the matrix-core filter runs over the whole bank once more for the listed queries with a
+//      FIXED threshold just below the k-th exact score found so far, every survivor is re-scored in float64 (k_final2);
+//   -> the EXACT list (k_exact, an exhaustive float64 sweep) when there is no usable k-th score.
+struct RedoLists {
+    int32_t* r_count;
+    int32_t* r_list;
+    float* tau2;
+    unsigned char* qpacked2;
+    int32_t* x_count;  // k_exact's list
+    int32_t* x_list;
+};
+
+// One workgroup per query: last selection, exact float64 re-score of the carried candidates, final order, output,
+// and the guard that proves the float32 filter lost nothing (see the file header).
+template <typename T, int SPEC>
+__global__ __launch_bounds__(SEL_THREADS, 4) void k_final(
+    const unsigned char* __restrict__ bank, int ks, const unsigned char* __restrict__ qpacked, int tnq, int kp, int k,
+    IscPerm pm, int64_t index_base, const float* __restrict__ norm_bound, const int32_t* __restrict__ qcount,
+    const Cand* __restrict__ qlist, const float* __restrict__ carry_s, const int32_t* __restrict__ carry_r,
+    const int32_t* __restrict__ carry_n, const int32_t* __restrict__ qflag, float* __restrict__ out_s,
+    int64_t* __restrict__ out_i, RedoLists rl, int32_t* __restrict__ status) {
+    __shared__ SelShared sh;
+    __shared__ double exact_dot[ISC_TOPK_MAX_K + 8];
+    __shared__ float fsc[ISC_TOPK_MAX_K + 8];
+    __shared__ int orig[ISC_TOPK_MAX_K + 8];
+    __shared__ double qnorm_sh;
+    __shared__ float kth_sh;
+    __shared__ int slot_sh;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = wg_select<SPEC>(sh, q, kp, qcount, qlist, carry_s, carry_r, carry_n);
+    bool redo = n < 0 || qflag[q] != 0;
+    const int nc = n < 0 ? 0 : n;
+
+    // this query's packed row: K step s at qrow_base + s * tnq * 128
+    const unsigned char* qrow_base = qpacked + ((size_t)(q / tnq) * ks * tnq + (q % tnq)) * ISC_KSTEP_BYTES;
+    if (tid < 64) {
+        const double nn = wave_query_norm<T>(qrow_base, ks, tnq);
+        if (tid == 0) qnorm_sh = sqrt(nn);
+    }
+    exact_dots<T>(bank, ks, qrow_base, tnq, nc, pm.n, [&](int c) { return isc_key_row(sh.topk[c]); },
+                  [&](int c, double dot) { exact_dot[c] = dot; });
     __syncthreads();
     const double qnorm = qnorm_sh;
     const double denom = fmax(qnorm, 1e-12);
+    const double bmax = norm_bound ? (double)*norm_bound : 1.001;
+
+    // ---- queries whose answer needs no search (and would flood every candidate list: ALL rows tie).  A zero query scores
+    // 0 against every row, a query with a non-finite norm NaN (any dot is +-inf or NaN, divided by inf or NaN): the order is
+    // by row index alone, i.e. the first k rows.  Only when the bank itself is finite (its norm bound is).
+    if ((qnorm == 0.0 || !(qnorm <= 1.7e308)) && bmax <= 1.7e308) {
+        if (tid < k) {
+            out_s[(size_t)q * k + tid] = qnorm == 0.0 ? 0.f : __uint_as_float(0x7fc00000u);
+            out_i[(size_t)q * k + tid] = (int64_t)tid + index_base;
+        }
+        return;
+    }
+
     if (tid < nc) {
         const int row = isc_key_row(sh.topk[tid]);
         fsc[tid] = (float)(exact_dot[tid] / denom);
         orig[tid] = (unsigned)row < (unsigned)pm.n ? (int)isc_perm_orig(pm, row) : 0x7ffffffe;
         if ((unsigned)row >= (unsigned)pm.n) redo = true;  // cannot happen; never trust such an entry
     }
+    if (tid == 0) kth_sh = __uint_as_float(0x7fc00000u);  // NaN until a k-th score exists
     __syncthreads();
     // rounding-error bound of a filter score: Dpad float32 accumulation steps, each off by at most 2^-23 of the running
     // magnitude (<= sum |q_i b_i| <= ||q|| * ||b||): one step of margin over round-to-nearest, whatever the order in
     // which the matrix core adds its 32 products
-    const double bmax = norm_bound ? (double)*norm_bound : 1.001;
     const double eps = (double)(ks * (ISC_KSTEP_BYTES / (int)sizeof(T))) * (1.0 / 8388608.0) * qnorm * bmax;
     // The bound is RELATIVE: it assumes every product and partial sum stays in float32's normal range (round to nearest at
     // every accumulation step of the matrix core is assumed too; status[2] < 1 is what the tests assert about it).  A query
     // of denormal scale loses product bits to underflow, one of huge scale can overflow a partial sum to inf / NaN while
     // the float64 score is finite -- and such rows are dropped silently by the filter.  |partial sum| <= ||q|| max||b||, so
-    // outside [1e-30, 1e37] (and for a NaN / inf norm) the query is answered by the exact pass instead.
-    if (!(qnorm >= 1e-30) || !(qnorm * bmax <= 1e37)) redo = true;
+    // outside [1e-30, 1e37] (and for a NaN / inf bound) no filter result is trusted: the exhaustive pass answers.
+    const bool filter_trusted = qnorm >= 1e-30 && qnorm * bmax <= 1e37;
     if (tid < nc) {
         const unsigned long long mykey = isc_make_key(fsc[tid], orig[tid]);
         int rank = 0;
@@ -1202,6 +1291,8 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void k_final(
     }
     redo = __syncthreads_or(redo ? 1 : 0) != 0;
     if (tid == 0) {
+        slot_sh = -1;
+        if (!filter_trusted) redo = true;
         if (!redo && (int64_t)nc < pm.n) {  // with every row of the bank carried the answer is exact as it stands
             if (nc < kp) {
                 redo = true;  // fewer candidates than asked for although the bank has more rows (NaN scores)
@@ -1212,10 +1303,104 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void k_final(
             }
         }
         if (redo) {
-            const int slot = atomicAdd(redo_count, 1);
-            redo_list[slot] = q;
             atomicAdd(&status[1], 1);
+            // Threshold of the redo filter, in the filter's units (raw dot products): a row that belongs to the answer has
+            // score >= kth, i.e. E / denom >= the float below kth (float32 rounding is monotone), and its filter score is
+            // A >= E - eps.  tau2 is rounded DOWN so that "A > tau2" keeps every such row, ties with kth included.
+            const float kth = kth_sh;
+            double t2 = (double)__uint_as_float(0x7fc00000u);
+            if (filter_trusted && kth == kth && fabsf(kth) <= 3.0e38f) {
+                const float kth_dn = nextafterf(kth, -INFINITY);
+                const double ed = (double)kth_dn * denom;
+                t2 = ed - eps - fabs(ed) * 1e-12;
+            }
+            if (t2 == t2 && fabs(t2) <= 3.0e38) {
+                float tf = (float)t2;
+                if ((double)tf >= t2) tf = nextafterf(tf, -INFINITY);
+                const int slot = atomicAdd(rl.r_count, 1);
+                rl.r_list[slot] = q;
+                rl.tau2[slot] = tf;
+                slot_sh = slot;
+            } else {  // no usable k-th score (fewer than k candidates, NaN / inf scores, untrusted filter)
+                const int slot = atomicAdd(rl.x_count, 1);
+                rl.x_list[slot] = q;
+                atomicAdd(&status[3], 1);
+            }
         }
+    }
+    __syncthreads();
+    const int slot = slot_sh;
+    if (slot >= 0) {  // this query's packed row -> row `slot` of the redo query tiles
+        unsigned char* dst = rl.qpacked2 + ((size_t)(slot / tnq) * ks * tnq + (slot % tnq)) * ISC_KSTEP_BYTES;
+        for (int i = tid; i < ks * 8; i += SEL_THREADS) {
+            const size_t off = (size_t)(i >> 3) * tnq * ISC_KSTEP_BYTES + (i & 7) * 16;
+            *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(qrow_base + off);
+        }
+    }
+}
+
+// One workgroup per redo SLOT (normally none: the launch exits at once).  The redo filter has collected every row whose
+// filter score exceeds tau2[slot] -- a superset of the rows that can belong to the answer (k_final) -- into the slot's list.
+// ALL of them are re-scored in float64 here, in place (the 8-byte list entry becomes the exact key), the best k by
+// (exact score desc, ORIGINAL row asc) are the answer: nothing is left to prove.  A list or candidate buffer that
+// overflowed (thousands of rows within rounding noise of the k-th score: a heavily duplicated row) hands the query to
+// k_exact.
+template <typename T>
+__global__ __launch_bounds__(SEL_THREADS, 4) void k_final2(
+    const unsigned char* __restrict__ bank, int ks, const unsigned char* __restrict__ qpacked2, int tnq, int k, IscPerm pm,
+    int64_t index_base, const int32_t* __restrict__ r_count, const int32_t* __restrict__ r_list,
+    const int32_t* __restrict__ qcount2, const int32_t* __restrict__ qflag2, Cand* __restrict__ qlist,
+    float* __restrict__ out_s, int64_t* __restrict__ out_i, int32_t* __restrict__ x_count, int32_t* __restrict__ x_list,
+    int32_t* __restrict__ status) {
+    const int slot = blockIdx.x;
+    if (slot >= *r_count) return;
+    __shared__ SelShared sh;
+    __shared__ double qnorm_sh;
+    const int tid = threadIdx.x;
+    const int q = r_list[slot];
+    const int cnt_all = qcount2[slot];
+    const int cnt = min(cnt_all, QCAP);
+    bool lost = qflag2[slot] != 0 || cnt_all > QCAP || cnt < k;
+    const unsigned char* qrow_base = qpacked2 + ((size_t)(slot / tnq) * ks * tnq + (slot % tnq)) * ISC_KSTEP_BYTES;
+    if (tid < 64) {
+        const double nn = wave_query_norm<T>(qrow_base, ks, tnq);
+        if (tid == 0) qnorm_sh = sqrt(nn);
+    }
+    __syncthreads();
+    const double denom = fmax(qnorm_sh, 1e-12);
+    Cand* list = qlist + (size_t)slot * QCAP;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(list);
+    int n = -1;
+    if (!lost) {
+        exact_dots<T>(bank, ks, qrow_base, tnq, cnt, pm.n, [&](int c) { return list[c].row; },
+                      [&](int c, double dot) {
+                          const int row = list[c].row;
+                          keys[c] = (unsigned)row < (unsigned)pm.n
+                                        ? isc_make_key((float)(dot / denom), (int)isc_perm_orig(pm, row))
+                                        : 0ull;
+                      });
+        __syncthreads();  // the keys were written by other waves of this workgroup (same CU, write-through L1)
+        unsigned long long key[SEL_PER + 1];
+#pragma unroll
+        for (int j = 0; j < SEL_PER; ++j)
+            key[j] = tid + SEL_THREADS * j < cnt
+                         ? __hip_atomic_load(keys + tid + SEL_THREADS * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                         : 0ull;
+        key[SEL_PER] = 0ull;
+        n = wg_select_keys(sh, key, k);
+    }
+    if (n < k) {  // overflow, or more than SURV_CAP rows tie around the k-th: the exhaustive pass answers
+        if (tid == 0) {
+            const int xs = atomicAdd(x_count, 1);
+            x_list[xs] = q;
+            atomicAdd(&status[3], 1);
+        }
+        return;
+    }
+    if (tid < k) {
+        const unsigned long long key = sh.topk[tid];
+        out_s[(size_t)q * k + tid] = isc_key_score(key);
+        out_i[(size_t)q * k + tid] = (int64_t)isc_key_row(key) + index_base;
     }
 }
 
@@ -1253,13 +1438,22 @@ int seg_tiles() {
 constexpr int seg_tiles() { return 128; }
 #endif
 
+// what a filter launch reads its queries / thresholds from and counts its survivors into: the search proper, or the redo
+struct FilterIO {
+    const unsigned char* qpacked;
+    const float* tau;
+    int32_t* qcount;
+    int32_t* qflag;
+    const int32_t* active;  // nullptr, or the device-side number of listed slots (redo): tiles past it exit at once
+};
+
 template <typename T, int TNQ>
-void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsigned char* bank, int ksteps,
-                   int32_t* status, hipStream_t stream) {
+void launch_filter(const Level& l, const Plan& p, const Workspace& w, const FilterIO& io, const unsigned char* bank,
+                   int ksteps, int32_t* status, hipStream_t stream) {
 #define ISC_LAUNCH_FILTER(DBG_, SAMPLE_)                                                                             \
     hipLaunchKernelGGL((k_dots_filter<T, TNQ, DBG_, SAMPLE_>), dim3(l.nchunks, p.qtiles), dim3(NTHREADS), 0, stream, \
-                       bank, l.r0, l.r1, l.tiles_per_chunk, l.ntiles, w.qpacked, ksteps, w.tau, p.qpad, w.seg_ent,   \
-                       w.qcount, w.qlist, p.kp, nslots_arg, w.qflag, status)
+                       bank, l.r0, l.r1, l.tiles_per_chunk, l.ntiles, io.qpacked, ksteps, io.tau, p.qpad, w.seg_ent,  \
+                       io.qcount, w.qlist, p.kp, nslots_arg, io.qflag, status, io.active)
     int nslots_arg = p.nslots;
     if (l.sample) {  // one tile per workgroup: the staging variant does not matter
 #ifdef ISC_ABLATION
@@ -1270,8 +1464,8 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
         Plan pa = p;
         pa.nslots |= abl << 16;
         hipLaunchKernelGGL((k_dots_filter<T, TNQ, 12, true>), dim3(l.nchunks, p.qtiles), dim3(NTHREADS), 0, stream, bank,
-                           l.r0, l.r1, l.tiles_per_chunk, l.ntiles, w.qpacked, ksteps, w.tau, p.qpad, w.seg_ent, w.qcount,
-                           w.qlist, p.kp, pa.nslots, w.qflag, status);
+                           l.r0, l.r1, l.tiles_per_chunk, l.ntiles, io.qpacked, ksteps, io.tau, p.qpad, w.seg_ent, io.qcount,
+                           w.qlist, p.kp, pa.nslots, io.qflag, status, io.active);
 #else
         if constexpr (TNQ == 64) {
             if (p.qtiles == 1) ISC_LAUNCH_FILTER(13, true);  // one query tile: non-temporal bank stream
@@ -1319,6 +1513,28 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const unsi
 #undef ISC_LAUNCH_FILTER
 }
 
+// With several query-tile workgroups per chunk, a long level runs as several launches over consecutive row ranges (same
+// thresholds, no selection in between): the partner workgroups that share a chunk's bank rows through their XCD's L2
+// drift apart as a launch goes on, and a kernel boundary realigns them for free (measured L2 -> fabric reads per search:
+// 1.9 x the algorithmic bytes with 594 tiles per chunk and launch, 1.3 x with 127 / 483).
+template <typename F>
+void for_each_segment(const Level& l, const Plan& p, F&& launch) {
+    int nseg = 1;
+    if (!l.sample && p.qtiles > 1) nseg = isc_ceil_div(l.tiles_per_chunk, seg_tiles());
+    const int64_t seg_rows = isc_ceil_div<int64_t>(isc_ceil_div<int64_t>(l.r1 - l.r0, nseg), TM) * TM;
+    for (int sg = 0; sg < nseg; ++sg) {
+        Level ls = l;
+        ls.r0 = l.r0 + sg * seg_rows;
+        ls.r1 = ls.r0 + seg_rows < l.r1 ? ls.r0 + seg_rows : l.r1;
+        if (ls.r0 >= ls.r1) break;
+        ls.ntiles = (int)isc_ceil_div<int64_t>(ls.r1 - ls.r0, TM);
+        const int want = l.nchunks < ls.ntiles ? l.nchunks : ls.ntiles;
+        ls.tiles_per_chunk = isc_ceil_div(ls.ntiles, want);
+        ls.nchunks = isc_ceil_div(ls.ntiles, ls.tiles_per_chunk);
+        launch(ls);
+    }
+}
+
 template <typename T>
 int run(const void* bank, int64_t n, int d, const void* queries, int q_total, int64_t ldq, int k, int64_t index_base,
         const float* norm_bound, float* out_s, int64_t* out_i, int32_t* status, void* ws_base, hipStream_t stream) {
@@ -1339,9 +1555,12 @@ int run(const void* bank, int64_t n, int d, const void* queries, int q_total, in
         const T* qptr = static_cast<const T*>(queries) + (int64_t)q0 * ldq;
         float* os = out_s + (size_t)q0 * k;
         int64_t* oi = out_i + (size_t)q0 * k;
+        const bool spec_all = q <= SMALL_Q;  // few queries: fetch every list blindly (one round trip); see wg_select
         hipLaunchKernelGGL(k_prep<T>, dim3(isc_ceil_div(p.qpad * ksteps * 8, 256)), dim3(256), 0, stream, qptr, ldq, q,
                            d, ksteps, p.qpad, p.tnq, w.qpacked, w.tau, w.carry_n, w.qcount, w.qflag,
-                           w.exact.redo_count, w.exact.done, status, q0 == 0 ? 1 : 0);
+                           w.exact.redo_count, w.exact.done, w.r_count, w.tau2, w.qcount2, w.qflag2, status,
+                           q0 == 0 ? 1 : 0);
+        const FilterIO io{w.qpacked, w.tau, w.qcount, w.qflag, nullptr};
         for (int li = 0; li < p.nlevels; ++li) {
             const Level& l = p.levels[li];
             // With several query-tile workgroups per chunk, a long level runs as several launches over consecutive row
@@ -1349,30 +1568,52 @@ int run(const void* bank, int64_t n, int d, const void* queries, int q_total, in
             // through their XCD's L2 drift apart as a launch goes on, and a kernel boundary realigns them for free
             // (measured L2 -> fabric reads per search: 1.9 x the algorithmic bytes with 594 tiles per chunk and launch,
             // 1.3 x with 127 / 483).
-            int nseg = 1;
-            if (!l.sample && p.qtiles > 1) nseg = isc_ceil_div(l.tiles_per_chunk, seg_tiles());
-            const int64_t seg_rows = isc_ceil_div<int64_t>(isc_ceil_div<int64_t>(l.r1 - l.r0, nseg), TM) * TM;
-            for (int sg = 0; sg < nseg; ++sg) {
-                Level ls = l;
-                ls.r0 = l.r0 + sg * seg_rows;
-                ls.r1 = ls.r0 + seg_rows < l.r1 ? ls.r0 + seg_rows : l.r1;
-                if (ls.r0 >= ls.r1) break;
-                ls.ntiles = (int)isc_ceil_div<int64_t>(ls.r1 - ls.r0, TM);
-                int want = l.nchunks < ls.ntiles ? l.nchunks : ls.ntiles;
-                ls.tiles_per_chunk = isc_ceil_div(ls.ntiles, want);
-                ls.nchunks = isc_ceil_div(ls.ntiles, ls.tiles_per_chunk);
+            for_each_segment(l, p, [&](const Level& ls) {
                 isc_timing_begin(ISC_KERNEL_DOTS_FILTER, stream);
-                if (p.tnq == 256) launch_filter<T, 256>(ls, p, w, bank_bytes, ksteps, status, stream);
-                else launch_filter<T, 64>(ls, p, w, bank_bytes, ksteps, status, stream);
+                if (p.tnq == 256) launch_filter<T, 256>(ls, p, w, io, bank_bytes, ksteps, status, stream);
+                else launch_filter<T, 64>(ls, p, w, io, bank_bytes, ksteps, status, stream);
                 isc_timing_end(ISC_KERNEL_DOTS_FILTER, stream);
+            });
+            if (li + 1 < p.nlevels) {
+                if (spec_all)
+                    hipLaunchKernelGGL(k_select<SEL_PER>, dim3(q), dim3(SEL_THREADS), 0, stream, w.qcount, w.qlist, p.kp,
+                                       w.tau, w.carry_s, w.carry_r, w.carry_n, w.qflag);
+                else
+                    hipLaunchKernelGGL(k_select<SEL_SPEC_MANY>, dim3(q), dim3(SEL_THREADS), 0, stream, w.qcount, w.qlist,
+                                       p.kp, w.tau, w.carry_s, w.carry_r, w.carry_n, w.qflag);
             }
-            if (li + 1 < p.nlevels)
-                hipLaunchKernelGGL(k_select, dim3(q), dim3(SEL_THREADS), 0, stream, w.qcount, w.qlist, p.kp, w.tau,
-                                   w.carry_s, w.carry_r, w.carry_n, w.qflag);
         }
-        hipLaunchKernelGGL(k_final<T>, dim3(q), dim3(SEL_THREADS), 0, stream, bank_bytes, ksteps, w.qpacked, p.tnq, p.kp,
-                           k, pm, index_base, norm_bound, w.qcount, w.qlist, w.carry_s, w.carry_r, w.carry_n, w.qflag, os,
-                           oi, w.exact.redo_count, w.exact.redo_list, status);
+        const RedoLists rl{w.r_count, w.r_list, w.tau2, w.qpacked2, w.exact.redo_count, w.exact.redo_list};
+        if (spec_all)
+            hipLaunchKernelGGL((k_final<T, SEL_PER>), dim3(q), dim3(SEL_THREADS), 0, stream, bank_bytes, ksteps, w.qpacked,
+                               p.tnq, p.kp, k, pm, index_base, norm_bound, w.qcount, w.qlist, w.carry_s, w.carry_r,
+                               w.carry_n, w.qflag, os, oi, rl, status);
+        else
+            hipLaunchKernelGGL((k_final<T, SEL_SPEC_MANY>), dim3(q), dim3(SEL_THREADS), 0, stream, bank_bytes, ksteps,
+                               w.qpacked, p.tnq, p.kp, k, pm, index_base, norm_bound, w.qcount, w.qlist, w.carry_s,
+                               w.carry_r, w.carry_n, w.qflag, os, oi, rl, status);
+        // ---- matrix-core redo of the listed queries (normally none: every launch below exits at once, ~1.5 us each):
+        // the whole bank as ONE level against the fixed thresholds tau2, survivors into the slots' lists, k_final2
+        {
+            const FilterIO rio{w.qpacked2, w.tau2, w.qcount2, w.qflag2, w.r_count};
+            Level all;
+            all.r0 = 0;
+            all.r1 = n;
+            all.sample = 0;
+            all.ntiles = (int)isc_ceil_div<int64_t>(n, TM);
+            int wgs = TARGET_WGS / p.qtiles;
+            if (wgs < 1) wgs = 1;
+            const int want = wgs < all.ntiles ? wgs : all.ntiles;
+            all.tiles_per_chunk = isc_ceil_div(all.ntiles, want);
+            all.nchunks = isc_ceil_div(all.ntiles, all.tiles_per_chunk);
+            for_each_segment(all, p, [&](const Level& ls) {
+                if (p.tnq == 256) launch_filter<T, 256>(ls, p, w, rio, bank_bytes, ksteps, status, stream);
+                else launch_filter<T, 64>(ls, p, w, rio, bank_bytes, ksteps, status, stream);
+            });
+            hipLaunchKernelGGL(k_final2<T>, dim3(q), dim3(SEL_THREADS), 0, stream, bank_bytes, ksteps, w.qpacked2, p.tnq, k,
+                               pm, index_base, w.r_count, w.r_list, w.qcount2, w.qflag2, w.qlist, os, oi,
+                               w.exact.redo_count, w.exact.redo_list, status);
+        }
         const int st = isc_exact_launch(sizeof(T) == 2 ? ISC_F16 : ISC_F32, bank, n, d, qptr, ldq, k, index_base,
                                         w.exact, os, oi, status, stream);
         if (st != ISC_OK) return st;

@@ -345,7 +345,9 @@ class EmbeddingBank:
         Returns `(scores float32 [Q, k], indices int64 [Q, k])`, best first, ties by lower row index.  The call
         only enqueues work: no host synchronisation, and the result is final -- queries the float32 filter cannot
         prove are redone exactly on the device.  `last_status` (int32[4], device) holds diagnostics: [0] overflowed
-        candidate buffers, [1] queries answered by the exact pass.  `check` is accepted for compatibility with the
+        candidate buffers, [1] queries the first pass could not prove (searched again: one more matrix-core pass over the
+        bank for all of them together), [3] queries answered by the exhaustive float64 sweep (about one bank sweep per
+        four such queries: a bank with thousands of exact copies of a row pays this for queries that hit them).  `check` is accepted for compatibility with the
         first version of this API and ignored.  Equivalent to `search_async(queries, k).result()`.
         """
         del check

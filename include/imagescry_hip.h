@@ -266,7 +266,10 @@ int isc_vit_assemble(const float* patch_embed, const float* cls_token, const flo
  * stored, result ordered by (score descending, row index ascending; NaN scores last).
  * The result is FINAL when the stream has run the call: the matrix-core pass is only a filter, the candidates are
  * re-scored in float64, a rounding-error guard proves per query that the filter lost nothing, and the queries it cannot
- * prove (or whose candidate buffers overflowed) are searched again exactly on the device.  No host round trip.
+ * prove (near-duplicate rows around the k-th neighbour, overflowed candidate buffers) are searched again on the device:
+ * one more matrix-core pass over the bank with a fixed threshold just below the k-th exact score found so far, EVERY
+ * survivor re-scored in float64 -- and, for what even that cannot hold (thousands of rows tied at the k-th score, NaN
+ * scores, queries of denormal or overflowing scale), the exhaustive float64 sweep.  No host round trip.
  *   bank         N rows of D values of `dtype` (ISC_F16 or ISC_F32) in the PACKED layout above (isc_bank_pack),
  *                16-byte aligned
  *   queries      row-major [Q, D] of the SAME dtype, leading dimension ldq (elements)
@@ -276,9 +279,9 @@ int isc_vit_assemble(const float* patch_embed, const float* cls_token, const flo
  *   out_scores   float   [Q, k]
  *   out_indices  int64_t [Q, k]
  *   status       int32_t [4] device words, diagnostics only:
- *                  [0] = candidate buffers that overflowed, [1] = queries answered by the exact float64 pass,
- *                  [2] = float bits of max |filter score - exact dot| / guard bound over the re-scored candidates
- *                        (must stay < 1), [3] reserved
+ *                  [0] = candidate buffers that overflowed, [1] = queries the first pass could not prove (searched
+ *                  again), [2] = float bits of max |filter score - exact dot| / guard bound over the re-scored
+ *                  candidates (must stay < 1), [3] = queries answered by the exhaustive float64 sweep (a subset of [1])
  * Calls with Q > 1024 run as passes of 1024 queries over the same workspace.  D <= ISC_SEARCH_MAX_D.
  */
 #define ISC_TOPK_MAX_K 120

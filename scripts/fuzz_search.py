@@ -63,7 +63,7 @@ while time.time() < t_end:
     qd = queries.to(dev)
     s, i = eb.search(qd, k)
     st = eb.last_status.cpu().tolist()
-    redone = st[1] - int(zeroq)  # queries answered by the exact pass (a zero query always is: every score ties)
+    redone = st[1]  # queries searched a second time (a zero query is answered directly: every score ties)
     fell = int(redone > 0)
     fallbacks += fell
     by_mode.setdefault(str(mode), [0, 0, 0, 0, 0])

@@ -288,9 +288,10 @@ def test_rounding_guard_catches_near_duplicates_of_the_kth_neighbour(dtype: torc
 
 def test_every_query_through_the_exact_pass(device: torch.device) -> None:
     """A bank of 2 000 distinct vectors each stored 100 times: the ten best rows of every query are exact copies of one
-    vector, more copies than the filter carries -- its choice among them cannot be proven, so EVERY query goes through
-    k_exact (64 listed queries = 16 sweeps of 782 tiles in 256 chunks, then the last-workgroup k-way merge).  The answer
-    must be the ten LOWEST original indices of the best vector, exactly as the oracle orders ties."""
+    vector, more copies than the filter carries -- its choice among them cannot be proven, so EVERY query is searched
+    again: ONE more matrix-core pass over the bank for all 64 together with the threshold fixed just below the k-th
+    exact score, all ~100 survivors per query re-scored in float64 (k_final2); none needs the exhaustive sweep.  The
+    answer must be the ten LOWEST original indices of the best vector, exactly as the oracle orders ties."""
     from oracle import c_oracle
 
     g = cases.gen(51)
@@ -302,7 +303,7 @@ def test_every_query_through_the_exact_pass(device: torch.device) -> None:
     exp_s, exp_i = c_oracle.cosine_topk(bank.float().numpy(), queries.float().numpy(), 10)
     _check(scores, indices, exp_s, exp_i)
     st = eb.last_status.cpu().tolist()
-    assert st[1] == 64, st
+    assert st[1] == 64 and st[3] == 0, st
     # the same through the explicit exhaustive entry point, and a second search on the same workspace stays correct
     es, ei = eb.search_exhaustive(queries.to(device), 10)
     assert torch.equal(ei, indices) and torch.equal(es, scores)
@@ -545,9 +546,9 @@ def test_large_k_on_a_multi_level_bank(k: int, dtype: torch.dtype, device: torch
     eb = EmbeddingBank(bank.to(device), dtype=dtype, normalize=True)
     scores, indices = eb.search(queries.to(device), k)
     st = eb.last_status.cpu().tolist()
-    # the zero query cannot be proven by the filter (every score ties: its candidate list may overflow too) and goes
-    # through the exact pass; duplicated rows may send a few more there -- never the whole call
-    assert 1 <= st[1] <= q // 4, st
+    # the zero query is answered directly (every score ties: rows 0..k-1); duplicated rows may send a few queries to the
+    # second pass -- never the whole call, and none to the exhaustive sweep
+    assert st[1] <= q // 4 and st[3] == 0, st
     exp_s, exp_i = c_oracle.cosine_topk(eb.bank.cpu().float().numpy(), queries.to(dtype).float().numpy(), k)
     _check(scores, indices, exp_s, exp_i)
     assert indices[5].cpu().tolist() == list(range(k))  # all-zero query: every score ties at 0, index order
@@ -578,3 +579,73 @@ def test_denormal_and_huge_scale_float32_queries(device: torch.device) -> None:
     s1, i1 = eb.search(unit.to(device), 10)
     assert int(eb.last_status.cpu()[1]) == 0
     assert torch.equal(i1[2:], indices[2:])
+
+
+@pytest.mark.parametrize("nq", [5, 200, 1500])
+def test_redo_pass_at_every_tile_shape(nq: int, device: torch.device) -> None:
+    """The matrix-core redo with the 64-query tile (5 queries), one 256-query tile (200) and a call of two passes with
+    four / two 256-query tiles (1500): every third query hits a vector stored 40 times, the others are ordinary; listed
+    and unlisted queries share the launch."""
+    from oracle import c_oracle
+
+    g = cases.gen(61 + nq)
+    base = torch.nn.functional.normalize(torch.randn(3000, 96, generator=g), dim=1)
+    dup = base[:50].repeat(40, 1)
+    bank = torch.cat([base, dup])[torch.randperm(5000, generator=g)].half()
+    queries = torch.randn(nq, 96, generator=g)
+    hit = torch.arange(0, nq, 3)
+    queries[hit] = base[hit % 50] + 0.01 * torch.randn(len(hit), 96, generator=g)
+    queries = queries.half()
+    eb = _bank(bank, device)
+    scores, indices = eb.search(queries.to(device), 10)
+    exp_s, exp_i = c_oracle.cosine_topk(bank.float().numpy(), queries.float().numpy(), 10)
+    _check(scores, indices, exp_s, exp_i)
+    st = eb.last_status.cpu().tolist()  # the status words of the LAST pass of the call
+    assert st[1] >= 1 and st[3] == 0, st
+
+
+def test_more_ties_than_the_redo_lists_hold(device: torch.device) -> None:
+    """20 000 identical rows (a uniform image patch indexed over and over) among 30 000: a query that hits them ties more
+    rows at its k-th score than the redo lists hold (8 192), so it -- and only it -- falls through to the exhaustive
+    float64 sweep; the answer is the ten lowest indices of the copies."""
+    from oracle import c_oracle
+
+    g = cases.gen(71)
+    rows = torch.nn.functional.normalize(torch.randn(30_000, 64, generator=g), dim=1)
+    patch = torch.nn.functional.normalize(torch.randn(64, generator=g), dim=0)
+    where = torch.randperm(30_000, generator=g)[:20_000]
+    rows[where] = patch
+    bank = rows.half()
+    queries = torch.randn(6, 64, generator=g)
+    queries[2] = patch * 3.0
+    queries = queries.half()
+    eb = _bank(bank, device)
+    scores, indices = eb.search(queries.to(device), 10)
+    exp_s, exp_i = c_oracle.cosine_topk(bank.float().numpy(), queries.float().numpy(), 10)
+    _check(scores, indices, exp_s, exp_i)
+    assert indices[2].cpu().tolist() == sorted(where.tolist())[:10]
+    st = eb.last_status.cpu().tolist()
+    assert st[3] >= 1 and st[1] >= st[3], st
+
+
+def test_zero_and_nonfinite_queries_need_no_second_search(device: torch.device) -> None:
+    """Every row ties for a zero query (score 0) and for a query with a non-finite norm (score NaN): the answer is the
+    first k rows by definition, written directly -- such queries (padding rows of a batch are zeros) must not be listed
+    for any second pass."""
+    bank, queries = cases.search_case(4000, 64, 6, torch.float16, seed=81)
+    queries = queries.float()
+    queries[1] = 0.0
+    queries[4, 7] = float("inf")
+    eb = _bank(bank, device)
+    scores, indices = eb.search(queries.to(device), 8)
+    st = eb.last_status.cpu().tolist()
+    assert st[1] == 0 and st[3] == 0, st
+    assert indices[1].cpu().tolist() == list(range(8)) and bool((scores[1] == 0).all())
+    assert indices[4].cpu().tolist() == list(range(8)) and bool(torch.isnan(scores[4]).all())
+    good = [0, 2, 3, 5]
+    exp_s, exp_i = search_oracle.cosine_topk(bank, queries.half()[good], 8)
+    np.testing.assert_array_equal(indices[good].cpu().numpy(), exp_i)
+    # with an index base (a shard) the trivial answer is the shard's first rows
+    eb2 = _bank(bank, device, index_base=1000, presharded=True)
+    s2, i2 = eb2.search(queries.to(device), 8)
+    assert i2[1].cpu().tolist() == list(range(1000, 1008))
