@@ -307,13 +307,16 @@ def query_sweep(bank: EmbeddingBank, rows: int, d: int, k: int, device: torch.de
         queries = torch.randn((q, d), generator=torch.Generator().manual_seed(SEED + q)).half().to(device)
         for _ in range(3):
             bank.search(queries, k)
-        steps = 20 if rows * q <= 2e8 else 5
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            bank.search(queries, k)
-        torch.cuda.synchronize()
-        sec = (time.perf_counter() - t0) / steps
+        steps = 20 if rows * q <= 2e9 else 8
+        rounds = []
+        for _ in range(3):  # three rounds, the median: one host hiccup in a 5 - 40 ms window moved a row by 20 %
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                bank.search(queries, k)
+            torch.cuda.synchronize()
+            rounds.append((time.perf_counter() - t0) / steps)
+        sec = sorted(rounds)[1]
         _lib.timing_enable(True)
         _lib.timing_read(_lib.ISC_KERNEL_DOTS_FILTER)
         for _ in range(steps):
@@ -332,6 +335,75 @@ def query_sweep(bank: EmbeddingBank, rows: int, d: int, k: int, device: torch.de
             "mfma_frac": r["mfma_frac"], "hbm_frac": r["hbm_frac"],
             "exact_pass_queries": int(bank.last_status[1].item()),
         })
+    return out
+
+
+def merge_us(bank: EmbeddingBank, q: int, k: int, device: torch.device, g: int = 8, reps: int = 50) -> float:
+    """Device time of one `isc_topk_merge` of `g` shards' partial results ([g, q, k], what every rank of a g-GPU search
+    runs behind its all-gather), microseconds, from HIP events over `reps` back-to-back launches on the current stream."""
+    gen = torch.Generator().manual_seed(SEED + q)
+    s = torch.randn((g, q, k), generator=gen).sort(dim=2, descending=True).values.to(device)
+    i = torch.randint(0, 1 << 40, (g, q, k), generator=gen).to(device)
+    for _ in range(3):
+        bank._merge_topk(s, i, k)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        bank._merge_topk(s, i, k)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(e0.elapsed_time(e1) * 1e3 / reps, 2)
+
+
+def time_search(bank: EmbeddingBank, queries: torch.Tensor, k: int, steps: int) -> tuple[float, list[int]]:
+    for _ in range(2):
+        bank.search(queries, k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bank.search(queries, k)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, bank.last_status.cpu().tolist()
+
+
+def bank_variants(n: int, d: int, q: int, k: int, device: torch.device, iid_ms: float) -> list[dict]:
+    """The same search on banks that are NOT exchangeable random rows (N = 1 only, outside the timed region of `value`):
+      dup8              every row stored 8 times -- the store holds an image indexed twice, uniform patches, ... -- so the
+                        k-th neighbour of every query ties with copies the filter cannot order: every query is searched
+                        a second time (one more matrix-core pass for all of them together, k_final2);
+      image_ordered_49  rows arrive in the reference's store order (record, h, w): 49 adjacent near-duplicate cells per
+                        image (src/imagescry/storage/operations.py:135-144)."""
+    out = []
+    queries = torch.randn((q, d), generator=torch.Generator().manual_seed(SEED)).half().to(device)
+
+    def run(name: str, rows: torch.Tensor, note: str) -> None:
+        bank = EmbeddingBank(rows, dtype=torch.float16, normalize=False)
+        del rows
+        torch.cuda.empty_cache()
+        sec, st = time_search(bank, queries, k, 5)
+        out.append({"bank": name, "rows": n, "queries": q, "ms_per_search": round(sec * 1e3, 3),
+                    "queries_per_s": round(q / sec, 1), "vs_iid": round(sec * 1e3 / iid_ms, 3),
+                    "searched_again_queries": st[1], "exhaustive_pass_queries": st[3],
+                    "overflowed_candidate_buffers": st[0], "note": note})
+        del bank
+        torch.cuda.empty_cache()
+
+    base = make_shard(0, n // 8, d, device, seed=SEED + 1000)
+    run("dup8", base.repeat(8, 1), "every row stored 8 times (original order: copy c of row r at c * N/8 + r)")
+    del base
+    cells = 49
+    images = (n + cells - 1) // cells
+    rows = torch.empty((n, d), dtype=torch.float16, device=device)
+    g = torch.Generator(device=device).manual_seed(SEED + 2000)
+    blk = 1 << 14  # images per block
+    for i0 in range(0, images, blk):
+        ni = min(blk, images - i0)
+        centre = torch.randn((ni, 1, d), generator=g, device=device)
+        cell = centre + 0.05 * torch.randn((ni, cells, d), generator=g, device=device)
+        flat = torch.nn.functional.normalize(cell, dim=2).half().reshape(ni * cells, d)
+        r0 = i0 * cells
+        rows[r0 : r0 + flat.shape[0]] = flat[: n - r0]
+    run("image_ordered_49", rows, "49 adjacent near-duplicate cells per image, in store order")
     return out
 
 
@@ -381,8 +453,17 @@ def bench_search(args: argparse.Namespace, rank: int, world: int, device: torch.
         if shard_rows >= 100_000:
             small = EmbeddingBank(make_shard(0, shard_rows, d, device), dtype=torch.float16, normalize=False)
             torch.cuda.empty_cache()
-            sweep += query_sweep(small, shard_rows, d, k, device, qs=(1, 16, 64, 1024))
+            shard_sweep = query_sweep(small, shard_rows, d, k, device, qs=(1, 16, 64, 1024))
+            for row in shard_sweep:  # what every rank of the 8-GPU search runs behind its all-gather
+                row["merge_us_g8"] = merge_us(small, row["queries"], k, device)
+            sweep += shard_sweep
             del small
+    variants = None
+    if world == 1 and not args.no_sweep and n >= 1_000_000:
+        del bank
+        torch.cuda.empty_cache()
+        variants = bank_variants(n, d, q, k, device, seconds / args.steps * 1e3)
+        bank = None
     traffic, traffic_src, per_step = measured_traffic({"bank_rows": n, "dim": d, "queries": q, "k": k, "rows_per_gpu": rows})
     if traffic_src:
         lps = max(roofline["launches_per_step"], 1e-9)
@@ -407,8 +488,10 @@ def bench_search(args: argparse.Namespace, rank: int, world: int, device: torch.
         "roofline": roofline,
         "selfcheck": check,
         "overflowed_candidate_buffers": status[0],
-        "exact_pass_queries": status[1],
+        "exact_pass_queries": status[1],  # queries the first pass could not prove (searched again on the device)
+        "exhaustive_pass_queries": status[3],
         "q_sweep": sweep,
+        "bank_variants": variants,
         "_bank": bank, "_queries": queries,
     }
 
@@ -694,11 +777,13 @@ def main() -> None:
             "config": primary["config"],
             "roofline": primary["roofline"],
         }
-        for key in ("selfcheck", "overflowed_candidate_buffers", "exact_pass_queries"):
+        for key in ("selfcheck", "overflowed_candidate_buffers", "exact_pass_queries", "exhaustive_pass_queries"):
             if key in primary:
                 line[key] = primary[key]
         if primary.get("q_sweep"):
             line["q_sweep"] = primary["q_sweep"]
+        if primary.get("bank_variants"):
+            line["bank_variants"] = primary["bank_variants"]
         if world == 1 and not args.no_cpu_baseline:
             if args.workload != "pipeline":
                 line["cpu_baseline"] = (cpu_baseline_search(args) if args.workload == "search"

@@ -7,7 +7,7 @@ python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/prof_trace/*/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
-names = ["k_dots_filter", "k_select", "k_final", "k_prep", "k_exact"]
+names = ["k_dots_filter", "k_select", "k_final2", "k_final", "k_prep", "k_exact"]
 seq = [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Grid_Size_X"]) for r in rows if any(n in r["Kernel_Name"] for n in names)]
 def short(n):
     for k in names:
