@@ -105,12 +105,19 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "isc_linear_centered": (
         c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
     ),
+    "isc_feature_sums_workspace_bytes": (c_int, [c_int64, c_int, POINTER(c_size_t)]),
+    "isc_feature_sums": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "isc_center_transpose": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "isc_gram_rows": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "isc_im2col_nchw": (
         c_int,
         [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     ),
     "isc_maxpool_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isc_global_avgpool_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isc_pool_linear_l2norm": (
+        c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]
+    ),
     "isc_gemm_f16": (
         c_int,
         [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p],

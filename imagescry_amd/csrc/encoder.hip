@@ -726,6 +726,85 @@ __global__ __launch_bounds__(256) void k_global_avgpool_nhwc(const float* __rest
     y[(size_t)blockIdx.y * C + c] = acc / (float)HW;
 }
 
+// The tail of a pooled encoder in one launch: global average pool -> linear -> (optional) L2 normalisation, HEAD_IMG
+// images per workgroup.  As three launches (pool, an M = B-row convolution on 24 workgroups with a serial 64-step K loop,
+// the row normalisation) this was 55 + 86 + 5 us at B = 512, C = 2048, E = 768.
+//   phase 1  pooled[img][c]: a thread owns channels t, t + 512, ...; sequential float32 sum over the positions, then one
+//            division -- the arithmetic of k_global_avgpool_nhwc, bit for bit;
+//   phase 2  feat[img][e] = bias[e] + sum_c pooled[img][c] w[e][c]: a wave owns outputs wave, wave + 8, ...; lanes along c
+//            with 16-byte weight loads (1 KiB contiguous per wave instruction, the weights stay in the L2), every load
+//            serves all the workgroup's images; one wave reduction per (output, image);
+//   phase 3  the arithmetic of k_l2norm_rows, bit for bit, on the first 256 threads per image.
+constexpr int HEAD_IMG = 2;
+constexpr int HEAD_THREADS = 512;
+__global__ __launch_bounds__(HEAD_THREADS) void k_pool_linear_l2norm(const float* __restrict__ x, int B, int HW, int C,
+                                                                     const float* __restrict__ w,
+                                                                     const float* __restrict__ bias, int E, int normalize,
+                                                                     float eps, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float head_lds[];
+    float* pooled = head_lds;              // [HEAD_IMG][C]
+    float* feat = head_lds + HEAD_IMG * C;  // [HEAD_IMG][E]
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = blockIdx.x * HEAD_IMG;
+    const int nimg = min(HEAD_IMG, B - b0);
+    for (int img = 0; img < HEAD_IMG; ++img)
+        for (int c = tid; c < C; c += HEAD_THREADS) {
+            float acc = 0.f;
+            if (img < nimg) {
+                const float* p = x + ((size_t)(b0 + img) * HW) * C + c;
+                for (int i = 0; i < HW; ++i) acc += p[(size_t)i * C];
+                acc = acc / (float)HW;
+            }
+            pooled[img * C + c] = acc;
+        }
+    __syncthreads();
+    for (int e = wave; e < E; e += HEAD_THREADS / 64) {
+        float acc[HEAD_IMG];
+#pragma unroll
+        for (int img = 0; img < HEAD_IMG; ++img) acc[img] = 0.f;
+        const float* wr = w + (size_t)e * C;
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 wv = *reinterpret_cast<const float4*>(wr + c);
+#pragma unroll
+            for (int img = 0; img < HEAD_IMG; ++img) {
+                const float4 pv = *reinterpret_cast<const float4*>(pooled + img * C + c);
+                acc[img] = fmaf(wv.x, pv.x, acc[img]);
+                acc[img] = fmaf(wv.y, pv.y, acc[img]);
+                acc[img] = fmaf(wv.z, pv.z, acc[img]);
+                acc[img] = fmaf(wv.w, pv.w, acc[img]);
+            }
+        }
+#pragma unroll
+        for (int img = 0; img < HEAD_IMG; ++img) {
+            const float tot = isc_wave_sum(acc[img]);
+            if (lane == 0) feat[img * E + e] = tot + (bias ? bias[e] : 0.f);
+        }
+    }
+    __syncthreads();
+    for (int img = 0; img < nimg; ++img) {
+        const float* p = feat + img * E;
+        float* o = out + (size_t)(b0 + img) * E;
+        if (!normalize) {
+            for (int i = tid; i < E; i += HEAD_THREADS) o[i] = p[i];
+            continue;
+        }
+        if (tid < 256) {  // k_l2norm_rows's own order: strided partial sums, wave butterflies, four wave sums in order
+            float acc = 0.f;
+            for (int i = tid; i < E; i += 256) {
+                const float v = p[i];
+                acc += v * v;
+            }
+            acc = isc_wave_sum(acc);
+            if (lane == 0) red[wave] = acc;
+        }
+        __syncthreads();
+        const float denom = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), eps);
+        for (int i = tid; i < E; i += HEAD_THREADS) o[i] = __fdiv_rn(p[i], denom);
+        __syncthreads();
+    }
+}
+
 // Squeeze-excitation gate of IMG images per workgroup: gate = sigmoid(w2 . silu(w1 . pooled + b1) + b2).  As two
 // launches of the convolution kernel these are M = B-row GEMMs on two or three workgroups with a serial 48-step K loop
 // (143 + 34 us for C = 1536, S = 64, B = 512).  This is a latency problem (0.8 MB of L2-resident weights per workgroup),
@@ -1026,6 +1105,15 @@ extern "C" int isc_linear_centered(const float* x, int64_t n, int F, const float
     return conv_launch(x, (int)n, 1, 1, F, w, K, 1, 1, 1, 0, bias, nullptr, mean, nullptr, ISC_ACT_NONE, out, stream);
 }
 
+// Gram matrix of the ROWS of a [F, n] matrix: gram[f1][f2] = sum_i xt[f1][i] * xt[f2][i].  The implicit-GEMM kernel with
+// the same operand on both sides: F "pixels" and F "output channels" of n "input channels" each.
+extern "C" int isc_gram_rows(const float* xt, int F, int64_t n, float* gram, void* stream) {
+    ISC_REQUIRE(xt && gram && F > 0 && n > 0 && n < (1ll << 31));
+    if (n % 32 != 0) return ISC_ERR_UNSUPPORTED;  // whole K steps: pad the sample axis with zero columns
+    return conv_launch(xt, F, 1, 1, (int)n, xt, F, 1, 1, 1, 0, nullptr, nullptr, nullptr, nullptr, ISC_ACT_NONE, gram,
+                       stream);
+}
+
 extern "C" int isc_nchw_to_nhwc(const float* x, int B, int C, int H, int W, int Cpad, float* y, void* stream) {
     ISC_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C);
     const size_t total = (size_t)B * H * W * Cpad;
@@ -1154,6 +1242,18 @@ extern "C" int isc_se_gate(const float* pooled, int B, int C, const float* w1, i
 #endif
     hipLaunchKernelGGL((k_se_gate<IMG>), dim3((unsigned)isc_ceil_div(B, IMG)), dim3(SE_THREADS), lds, isc_stream(stream),
                        pooled, B, C, w1, ld1, b1, S, w2, ld2, b2, lpr, gate);
+    return isc_launch_status();
+}
+
+extern "C" int isc_pool_linear_l2norm(const float* x, int B, int H, int W, int C, const float* w, const float* bias, int E,
+                                      int normalize, float eps, float* out, void* stream) {
+    ISC_REQUIRE(x && w && out && B > 0 && H > 0 && W > 0 && C > 0 && E > 0);
+    if (C % 4 != 0) return ISC_ERR_UNSUPPORTED;
+    if (!isc_aligned(w, 16)) return ISC_ERR_ALIGNMENT;
+    const size_t lds = (size_t)HEAD_IMG * ((size_t)C + E) * sizeof(float);
+    if (lds > 64 * 1024) return ISC_ERR_UNSUPPORTED;  // C + E <= 8192
+    hipLaunchKernelGGL(k_pool_linear_l2norm, dim3(isc_ceil_div(B, HEAD_IMG)), dim3(HEAD_THREADS), lds, isc_stream(stream), x,
+                       B, H * W, C, w, bias, E, normalize, eps, out);
     return isc_launch_status();
 }
 

@@ -1,10 +1,12 @@
-"""Principal component analysis with the projection on MI355X.
+"""Principal component analysis on MI355X: fit and projection.
 
 Same constructor arguments, attributes and behaviour as the reference `PCA`
-(src/imagescry/models/decomposition.py:11-180).  `fit` runs the SVD on the host (one-off, LAPACK through torch,
-exactly the reference's calls); `transform` / `forward` -- the step the reference applies to every embedding
-batch right after the hot path (src/imagescry/models/pipelines.py:76-84) -- runs in the HIP kernel behind
-`isc_linear_centered`: `(x - feature_means) @ component_vectors` with the centring done before the product.
+(src/imagescry/models/decomposition.py:11-180).  `fit` keeps everything sample-sized on the GPU -- float64 feature sums,
+centred + transposed chunks and their Gram matrices on the f32 matrix cores -- and leaves the host the `F x F`
+symmetric eigenproblem, where the reference runs an SVD of the whole `[N, F]` matrix on the host.  `transform` /
+`forward` -- the step the reference applies to every embedding batch right after the hot path
+(src/imagescry/models/pipelines.py:76-84) -- runs in the HIP kernel behind `isc_linear_centered`:
+`(x - feature_means) @ component_vectors` with the centring done before the product.
 """
 
 from __future__ import annotations
@@ -58,35 +60,85 @@ class PCA:
         num_components = self.num_components if self.fitted else "not fitted"
         return f"{self.__class__.__name__}(num_features={num_features}, num_components={num_components})"
 
-    # ------------------------------------------------------------------ fit (host)
+    # ------------------------------------------------------------------ fit (device + an F x F eigenproblem)
+    GRAM_CHUNK_ROWS = 32768  # samples per Gram launch: each chunk's sum is float32, the chunks are added in float64
+
     def fit(self, x: Tensor) -> "PCA":
-        """Centre (not scale) the features, SVD, keep the components the constructor arguments ask for
-        (reference: decomposition.py:94-148).  `x` may live on any device; the SVD runs on the host."""
+        """Principal axes of the centred (not scaled) rows and how many of them the constructor arguments ask for.
+
+        The reference centres `x` and takes `torch.linalg.svd` of the `[N, F]` matrix on the host
+        (decomposition.py:118-146).  Here everything N-sized runs on the GPU, in three kernels: per-feature sums in
+        float64 (`isc_feature_sums`), the centred rows written transposed chunk by chunk (`isc_center_transpose`), and
+        the `F x F` Gram matrix of every chunk on the f32 matrix cores (`isc_gram_rows`), added up in float64.  The
+        eigenvectors of the Gram matrix ARE the right singular vectors, its eigenvalues the squared singular values, so
+        the one thing left for the host is the `F x F` symmetric eigenproblem (LAPACK, float64).  Outputs as the
+        reference: `feature_means [1, F]`, `explained_variance [min(N, F)]`, `component_vectors [F, K]`, K chosen by
+        the same rule (decomposition.py:133-142).  A principal axis is defined up to its sign; the sign is fixed here by
+        making each component's largest-magnitude entry positive.
+        """
         if not isinstance(x, Tensor) or not x.dtype.is_floating_point or x.ndim != 2:
             raise TypeError("x must be a floating point [num_samples, num_features] tensor")
         num_samples, num_features = x.shape
         if num_samples < 2:
             raise ValueError(f"num_samples must be at least 2, got {num_samples}")
-        xh = x.detach().cpu()
-        self._num_features = num_features
-        self.feature_means = xh.mean(dim=0, keepdim=True)
-        x_centered = xh - self.feature_means
-        _, s, vt = torch.linalg.svd(x_centered)
-        eigenvalues = s**2 / (num_samples - 1)
-        total_variance = torch.sum(eigenvalues)
-        self.explained_variance = eigenvalues / total_variance
-        cumulative = torch.cumsum(self.explained_variance, dim=0)
-        needed = int(torch.sum(cumulative < self.min_explained_variance).item() + 1)
+        if x.device.type != "cuda" and self._device.type == "cuda":
+            x = x.to(self._device)  # a host tensor handed to a model that lives on the GPU
+        _lib.require_device(x, "x")  # no CPU fallback
+        dev = x.device
+        lib = _lib.load()
+        xf = x.detach().float()
+        if xf.stride(1) != 1:
+            xf = xf.contiguous()
+        n, f = num_samples, num_features
+        fpad = (f + 3) // 4 * 4
+        with torch.cuda.device(dev):
+            stream = _lib.stream_handle(dev)
+            need = _lib.c_size_t()
+            _lib.check(lib.isc_feature_sums_workspace_bytes(n, f, need), "isc_feature_sums_workspace_bytes")
+            ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+            sums = torch.empty(f, dtype=torch.float64, device=dev)
+            _lib.check(lib.isc_feature_sums(xf.data_ptr(), n, f, xf.stride(0), sums.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            stream), "isc_feature_sums")
+            mean = (sums / n).float()  # what the reference subtracts: a float32 mean
+            # rows per chunk: F * rows < 2^31 (32-bit element offsets in the kernel), whole K steps of 32 samples
+            chunk = max(32, min(self.GRAM_CHUNK_ROWS, ((2**31 - 1) // fpad) // 32 * 32))
+            ld = (min(chunk, n) + 31) // 32 * 32
+            xt = torch.empty((fpad, ld), dtype=torch.float32, device=dev)
+            gram_chunk = torch.empty((fpad, fpad), dtype=torch.float32, device=dev)
+            gram = torch.zeros((fpad, fpad), dtype=torch.float64, device=dev)
+            for r0 in range(0, n, chunk):
+                rows = min(chunk, n - r0)
+                ldn = (rows + 31) // 32 * 32
+                blk = xf[r0 : r0 + rows]
+                _lib.check(lib.isc_center_transpose(blk.data_ptr(), rows, f, xf.stride(0), mean.data_ptr(), xt.data_ptr(),
+                                                    fpad, ldn, stream), "isc_center_transpose")
+                _lib.check(lib.isc_gram_rows(xt.data_ptr(), fpad, ldn, gram_chunk.data_ptr(), stream), "isc_gram_rows")
+                gram += gram_chunk.double()
+        g = gram[:f, :f].cpu()
+        g = (g + g.T) * 0.5
+        evals, evecs = torch.linalg.eigh(g)  # ascending; float64
+        evals = torch.flip(evals, dims=(0,)).clamp_min(0.0)
+        evecs = torch.flip(evecs, dims=(1,))
+        lead = evecs.abs().argmax(dim=0)
+        evecs = evecs * torch.sign(evecs[lead, torch.arange(f)]).masked_fill_(evecs[lead, torch.arange(f)] == 0, 1.0)
+        rank = min(n, f)  # the reference's SVD returns min(N, F) singular values
+        eigenvalues = evals[:rank] / (n - 1)
+        explained = eigenvalues / eigenvalues.sum()
+        cumulative = torch.cumsum(explained, dim=0)
+        needed = int((cumulative < self.min_explained_variance).sum().item()) + 1
         num_components = max(self.min_num_components, needed)
         if self.max_num_components is not None:
             num_components = min(self.max_num_components, num_components)
+        num_components = min(num_components, f)
+        self._num_features = f
         self._num_components = num_components
-        self.component_vectors = vt[:num_components, :].T.contiguous()
+        self.feature_means = mean.reshape(1, f)
+        self.explained_variance = explained.float().to(dev)
+        self.component_vectors = evecs[:, :num_components].float().contiguous().to(dev)
         self._fitted = True
-        self.hparams.update({"num_features": num_features, "num_components": num_components})
+        self.hparams.update({"num_features": f, "num_components": num_components})
+        self._device = dev
         self._packed = None
-        if x.device.type == "cuda":
-            self.to(x.device)
         return self
 
     # ------------------------------------------------------------------ device placement

@@ -97,11 +97,17 @@ class EmbeddingModule(ABC):
         if self._fused_predict_ok():
             # preprocess and forward back to back: the normalisation writes the stem's channels-last layout directly
             # (same values as `forward(preprocess(images))`, one pass less over the batch)
-            x = self._forward_nhwc4(self.preprocess(batch.images, _nhwc4=True))
+            x4 = self.preprocess(batch.images, _nhwc4=True)
+            if self._head_normalizes:  # the encoder's last kernel applies F.normalize itself (same bits)
+                return EmbeddingBatch(indices=batch.indices, embeddings=self._forward_nhwc4(x4, normalized=True))
+            x = self._forward_nhwc4(x4)
         else:
             x = self.forward(self.preprocess(batch.images))
         x = l2_normalize_channels(x)
         return EmbeddingBatch(indices=batch.indices, embeddings=x)
+
+    # an encoder whose `_forward_nhwc4(x4, normalized=True)` returns the L2-normalised embedding (fused into its tail)
+    _head_normalizes = False
 
     def _forward_nhwc4(self, x4: Tensor) -> Tensor:
         """`forward` from the stem's own input layout `[B, H, W, 4]` (RGB + a zero channel); optional."""
@@ -242,7 +248,9 @@ class ResNet50Embedder(EmbeddingModule):
             _lib.check(lib_nchw_to_nhwc(x, x4), "isc_nchw_to_nhwc")
         return self._forward_nhwc4(x4)
 
-    def _forward_nhwc4(self, x4: Tensor) -> Tensor:
+    _head_normalizes = True
+
+    def _forward_nhwc4(self, x4: Tensor, normalized: bool = False) -> Tensor:
         _lib.require_device(x4, "x")
         if self.device != x4.device:
             raise ValueError(f"module is on {self.device} but the input is on {x4.device}; call .to() first")
@@ -254,10 +262,10 @@ class ResNet50Embedder(EmbeddingModule):
         out = torch.empty((b, self._embedding_dim), dtype=torch.float32, device=x4.device)
         with torch.cuda.device(x4.device):
             for b0 in range(0, b, chunk):
-                out[b0 : b0 + chunk] = self._forward_chunk(x4[b0 : b0 + chunk])
+                self._forward_chunk(x4[b0 : b0 + chunk], out[b0 : b0 + chunk], normalized)
         return out[:, :, None, None]
 
-    def _forward_chunk(self, x4: Tensor) -> Tensor:
+    def _forward_chunk(self, x4: Tensor, out: Tensor, normalized: bool) -> None:
         lib = _lib.load()
         stream = _lib.stream_handle(x4.device)
         net = self._net
@@ -281,11 +289,11 @@ class ResNet50Embedder(EmbeddingModule):
             t = _conv(y, blk.conv1, _lib.ISC_ACT_RELU)
             t = _conv(t, blk.conv2, _lib.ISC_ACT_RELU)
             y = _conv(t, blk.conv3, _lib.ISC_ACT_RELU, residual=identity)
+        # tail in one launch: global average pool -> projection (-> F.normalize when predict_step asks for it)
         bb, hh, ww, cc = y.shape
-        feat = torch.empty((bb, 1, 1, cc), dtype=torch.float32, device=dev)
-        _lib.check(lib.isc_global_avgpool_nhwc(y.data_ptr(), bb, hh, ww, cc, feat.data_ptr(), stream),
-                   "isc_global_avgpool_nhwc")
-        return _conv(feat, net.fc, _lib.ISC_ACT_NONE).reshape(bb, self._embedding_dim)
+        st = lib.isc_pool_linear_l2norm(y.data_ptr(), bb, hh, ww, cc, net.fc.weight.data_ptr(), net.fc.bias.data_ptr(),
+                                        self._embedding_dim, int(normalized), 1e-12, out.data_ptr(), stream)
+        _lib.check(st, "isc_pool_linear_l2norm")
 
 
 class EfficientNetEmbedder(EmbeddingModule):

@@ -212,6 +212,14 @@ int isc_maxpool_nhwc(const float* x, int B, int H, int W, int C, int R, int stri
 /* global average pooling, NHWC float [B,H,W,C] -> [B,C]. */
 int isc_global_avgpool_nhwc(const float* x, int B, int H, int W, int C, float* y, void* stream);
 
+/* The tail of a pooled encoder in ONE launch: out[b] = linear(mean over (H, W) of x[b]) [/ max(||.||_2, eps) when
+ * `normalize`]: global average pool, projection and the `F.normalize(x, p=2, dim=1)` of the reference's predict_step
+ * (src/imagescry/models/embedding.py:70-76) for an embedder whose output map is [B, E, 1, 1].  x float NHWC
+ * [B, H, W, C], w float [E, C] (16-byte aligned), bias float [E] or NULL, out float [B, E]; C % 4 == 0, C + E <= 8192.
+ * The pool and the normalisation reproduce isc_global_avgpool_nhwc and isc_l2norm_channels bit for bit. */
+int isc_pool_linear_l2norm(const float* x, int B, int H, int W, int C, const float* w, const float* bias, int E,
+                           int normalize, float eps, float* out, void* stream);
+
 /* ---- transformer encoder blocks (ViT-B/16, BASELINE.json configs[4]); fp16 operands, float32 accumulation -------
  * The reference's encoder is any `EmbeddingModule.forward` (models/embedding.py:91-104); these are the blocks a
  * ViT forward is composed of (torch.nn.Linear / LayerNorm / scaled_dot_product_attention in a torch build). */
@@ -255,6 +263,28 @@ int isc_patchify_f16(const float* x, int B, int C, int H, int W, int patch, void
 /* tokens[b][0] = cls + pos[0]; tokens[b][t] = patch_embed[b * (T - 1) + t - 1] + pos[t]; all float32, D % 4 == 0. */
 int isc_vit_assemble(const float* patch_embed, const float* cls_token, const float* pos_embed, int B, int T, int D,
                      float* tokens, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * PCA fit (reference src/imagescry/models/decomposition.py:118-131: mean, centring, SVD of the [N, F] rows on
+ * the host).  The N-sized work runs here -- float64 feature sums, centred + transposed chunks, their F x F Gram matrices
+ * on the f32 matrix cores; the F x F eigenproblem is the host's (imagescry_amd/decomposition.py).
+ * ------------------------------------------------------------------------------------------- */
+
+/* sums[f] = sum_i x[i][f] in float64, bit-reproducible (fixed two-stage order).  x float [n, F] with row stride ldx.
+ * Replaces `x.mean(dim=0, keepdim=True)` (decomposition.py:120). */
+int isc_feature_sums_workspace_bytes(int64_t n, int F, size_t* bytes);
+int isc_feature_sums(const float* x, int64_t n, int F, int64_t ldx, double* sums, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* xt[f][i] = x[i][f] - mean[f] (i < n), 0 for n <= i < ldn and for F <= f < Fpad; xt float [Fpad, ldn].
+ * Replaces `x - self.feature_means` (decomposition.py:123) and hands the Gram kernel its K-contiguous operand. */
+int isc_center_transpose(const float* x, int64_t n, int F, int64_t ldx, const float* mean, float* xt, int Fpad,
+                         int64_t ldn, void* stream);
+
+/* gram[f1][f2] = sum_i xt[f1][i] * xt[f2][i] on the f32 matrix cores (k_conv_f32 with xt as both operands); xt float
+ * [F, n], n % 32 == 0, F % 4 == 0, F * n < 2^31; gram float [F, F].  The right singular vectors / singular values the
+ * reference takes from `torch.linalg.svd(x_centered)` (decomposition.py:126) are the eigenpairs of this matrix. */
+int isc_gram_rows(const float* xt, int F, int64_t n, float* gram, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Search

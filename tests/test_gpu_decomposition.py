@@ -1,5 +1,8 @@
-"""GPU parity of `PCA.transform` (C ABI: isc_linear_centered) and of `EmbeddingPCAPipeline.predict_step` against
-the oracle's restatement of the reference (decomposition.py:78-91, pipelines.py:63-86)."""
+"""GPU parity of `PCA.fit` (C ABI: isc_feature_sums, isc_center_transpose, isc_gram_rows + a host eigh), `PCA.transform`
+(isc_linear_centered) and `EmbeddingPCAPipeline.predict_step` against the oracle's restatement of the reference
+(decomposition.py:78-148, pipelines.py:63-86).  The reference takes an SVD of the centred rows, the product the
+eigenvectors of their Gram matrix: the same axes up to sign, so component vectors are compared after aligning signs, and
+where eigenvalues repeat (an eigenSPACE has no preferred basis) through the subspace they span."""
 
 from __future__ import annotations
 
@@ -18,18 +21,45 @@ from oracle import decomposition_oracle, encoder_oracle  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,f,kmax", [(1000, 4, None), (777, 768, 64), (300, 1280, 37), (5, 96, 3)])
-def test_transform_matches_oracle(n: int, f: int, kmax, device: torch.device) -> None:
+def _aligned(components: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
+    """`components` with each column's sign flipped to agree with `ref`'s."""
+    sign = torch.sign((components * ref).sum(dim=0))
+    return components * torch.where(sign == 0, torch.ones_like(sign), sign)
+
+
+@pytest.mark.parametrize("n,f,kmax", [(1000, 4, None), (777, 768, 64), (300, 1280, 37), (5, 96, 3), (70_000, 64, 8)])
+def test_fit_and_transform_match_oracle(n: int, f: int, kmax, device: torch.device) -> None:
     from imagescry_amd import PCA
 
     g = cases.gen(n + f)
-    # correlated features with a large common offset: centring BEFORE the product matters for the rounding
+    # correlated features with a large common offset: centring BEFORE the products matters for the rounding
     x = torch.randn(n, f, generator=g) @ torch.randn(f, f, generator=g) * 0.1 + 50.0
-    pca = PCA(max_num_components=kmax, min_explained_variance=1.0).fit(x).to(device)
+    pca = PCA(max_num_components=kmax, min_explained_variance=1.0).fit(x.to(device))
     ref = decomposition_oracle.fit(x, max_num_components=kmax, min_explained_variance=1.0)
+    assert pca.device == device and pca.num_features == f
     assert pca.num_components == ref.num_components
+    assert pca.feature_means.shape == (1, f) and pca.explained_variance.shape == ref.explained_variance.shape
+    torch.testing.assert_close(pca.feature_means.cpu(), ref.feature_means, rtol=1e-6, atol=0)
+    torch.testing.assert_close(pca.explained_variance.cpu(), ref.explained_variance, rtol=2e-3, atol=1e-7)
+    k = pca.num_components
+    comp = pca.component_vectors.cpu()
+    assert comp.shape == (f, k)
+    torch.testing.assert_close(comp.T @ comp, torch.eye(k), rtol=0, atol=1e-5)  # orthonormal
+    # well separated leading axes agree with the SVD's up to sign
+    lead = min(k, 3)
+    torch.testing.assert_close(_aligned(comp[:, :lead], ref.component_vectors[:, :lead]), ref.component_vectors[:, :lead],
+                               rtol=0, atol=2e-3)
+    # every kept axis lies in the span of the reference's axes with eigenvalues at least as large, and vice versa: the
+    # projectors agree
+    if k < min(n - 1, f):
+        p_got, p_ref = comp @ comp.T, ref.component_vectors @ ref.component_vectors.T
+        gap = float(ref.explained_variance[k - 1] - ref.explained_variance[k]) / float(ref.explained_variance[0])
+        if gap > 1e-3:
+            torch.testing.assert_close(p_got, p_ref, rtol=0, atol=5e-3)
+    # the projection with the product's OWN fitted parameters equals the reference expression on them
     got = pca.transform(x.to(device)).cpu()
-    exp = ref.transform(x)
+    own = decomposition_oracle.FittedPCA(pca.feature_means.cpu(), pca.explained_variance.cpu(), comp)
+    exp = own.transform(x)
     assert got.shape == exp.shape and got.dtype == torch.float32
     scale = float(exp.abs().max())
     np.testing.assert_allclose(got.numpy(), exp.numpy(), rtol=0, atol=2e-5 * max(scale, 1.0))
@@ -37,6 +67,40 @@ def test_transform_matches_oracle(n: int, f: int, kmax, device: torch.device) ->
         pca.transform(x[:, :-1].to(device))
     with pytest.raises(Exception):
         pca.transform(x)  # CPU tensor: no fallback
+
+
+def _reference_features(correlated: bool) -> torch.Tensor:
+    from torch.distributions import MultivariateNormal
+
+    torch.manual_seed(1234)
+    cov = (torch.tensor([[1.0, 0.5, 0.0, 0.0], [0.5, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, -0.5], [0.0, 0.0, -0.5, 1.0]])
+           if correlated else torch.eye(4))
+    return MultivariateNormal(loc=torch.tensor([0.0, 1.0, -1.0, 0.0]), covariance_matrix=cov).sample((1000,))
+
+
+@pytest.mark.parametrize("correlated,min_explained_variance,expected",
+                         [(False, 0.2, 1), (False, 0.4, 2), (False, 0.6, 3), (False, 1.0, 4),
+                          (True, 0.2, 1), (True, 0.4, 2), (True, 0.6, 2), (True, 0.8, 3), (True, 1.0, 4)])
+def test_reference_pca_cases_on_gpu(correlated: bool, min_explained_variance: float, expected: int,
+                                    device: torch.device) -> None:
+    """The reference's own parametrisation (tests/test_models/test_decomposition.py:42-124): seeds, distributions, expected
+    component counts, the explained-variance promise and the decorrelation of the projected features."""
+    from imagescry_amd import PCA
+
+    x = _reference_features(correlated)
+    pca = PCA(min_explained_variance=min_explained_variance).fit(x.to(device))
+    ref = decomposition_oracle.fit(x, min_explained_variance=min_explained_variance)
+    assert pca.fitted and pca.num_features == 4 and pca.num_components == expected == ref.num_components
+    assert pca.hparams["num_components"] == expected and repr(pca) == f"PCA(num_features=4, num_components={expected})"
+    torch.testing.assert_close(pca.explained_variance.cpu(), ref.explained_variance, rtol=1e-4, atol=1e-6)
+    assert pca.explained_variance[:expected].sum().item() >= min_explained_variance - 1e-6
+    projected = pca.transform(x.to(device)).cpu()
+    assert projected.shape == (1000, expected)
+    if expected > 1:
+        corr = torch.abs(torch.corrcoef(projected.T))
+        assert torch.all(torch.tril(corr, diagonal=-1) <= 1e-4)
+    capped = PCA(max_num_components=2, min_explained_variance=1.0).fit(x.to(device))
+    assert capped.num_components == 2  # the cap wins over the explained-variance request
 
 
 def test_reference_decorrelation_property_on_gpu(device: torch.device) -> None:
@@ -63,7 +127,7 @@ def test_pipeline_predict_step(device: torch.device) -> None:
     emb = model.predict_step(ImageBatch(indices=torch.arange(24), images=fit_images).to(device))
     with pytest.raises(ValueError):
         EmbeddingPCAPipeline(embedding_model=model, pca=PCA())
-    pca = PCA(max_num_components=8, min_explained_variance=1.0).fit(emb.get_flat_vectors())
+    pca = PCA(max_num_components=8, min_explained_variance=1.0).fit(emb.get_flat_vectors())  # device rows
     pipe = EmbeddingPCAPipeline(embedding_model=model, pca=pca)
     images = cases.images_u8((3, 3, 64, 64), seed=32)
     batch = ImageBatch(indices=torch.tensor([4, 2, 9]), images=images)

@@ -345,3 +345,33 @@ def test_predict_step_equals_the_unfused_composition(name: str, device: torch.de
     assert out.shape == ref.shape
     assert torch.equal(out, ref)
 
+
+
+@pytest.mark.parametrize("b,hw,c,e", [(5, (7, 7), 2048, 768), (1, (3, 2), 64, 8), (8, (1, 1), 512, 1000)])
+def test_fused_pool_linear_l2norm_tail(b: int, hw: tuple[int, int], c: int, e: int, device: torch.device) -> None:
+    """`isc_pool_linear_l2norm` (one launch) against its three-launch composition -- isc_global_avgpool_nhwc,
+    isc_conv2d_nhwc 1 x 1, isc_l2norm_channels -- and against torch: pooled values and the normalisation arithmetic are
+    the same bits as the separate kernels', the projection agrees with a float64 product to float32 rounding."""
+    from imagescry_amd import _lib
+    from imagescry_amd.embedding import l2_normalize_channels
+
+    g = cases.gen(b + c)
+    h, w = hw
+    x = torch.randn(b, h, w, c, generator=g)
+    wt = torch.randn(e, c, generator=g) / c**0.5
+    bias = torch.randn(e, generator=g)
+    lib = _lib.load()
+    xd, wd, bd = x.to(device), wt.to(device), bias.to(device)
+    stream = _lib.stream_handle(device)
+    plain = torch.empty((b, e), device=device)
+    normed = torch.empty((b, e), device=device)
+    for out, flag in ((plain, 0), (normed, 1)):
+        _lib.check(lib.isc_pool_linear_l2norm(xd.data_ptr(), b, h, w, c, wd.data_ptr(), bd.data_ptr(), e, flag, 1e-12,
+                                              out.data_ptr(), stream), "isc_pool_linear_l2norm")
+    pooled = torch.empty((b, c), device=device)
+    _lib.check(lib.isc_global_avgpool_nhwc(xd.data_ptr(), b, h, w, c, pooled.data_ptr(), stream), "avgpool")
+    exp = (pooled.cpu().double() @ wt.double().T + bias.double()).float()
+    assert _rel_err(plain.cpu(), exp) < 2e-6
+    # the normalisation: the same bits as the separate kernel applied to the fused projection
+    assert torch.equal(normed, l2_normalize_channels(plain[:, :, None, None]).reshape(b, e))
+    np.testing.assert_allclose(normed.cpu().numpy(), F.normalize(exp, dim=1).numpy(), rtol=0, atol=1e-6)
