@@ -39,11 +39,16 @@ def _stale(target: Path, deps: list[Path]) -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> Path:
+def build(force: bool = False, verbose: bool = True, ablation: bool = False, variant: str = "",
+          defines: tuple[str, ...] = ()) -> Path:
+    """`variant` + `defines`: an experiment build `libimagescry_hip_<variant>.so` with extra -D flags (scripts/ only,
+    always an ablation build: the binding refuses it without ISC_ALLOW_ABLATION=1)."""
     hipcc = _hipcc()
-    obj_dir = CSRC / "build_ablation" if ablation else OBJ
-    lib = ABLATION_LIB if ablation else LIB
-    flags = [*FLAGS, "-DISC_ABLATION"] if ablation else FLAGS
+    if variant:
+        ablation = True
+    obj_dir = CSRC / (f"build_{variant}" if variant else "build_ablation" if ablation else "build")
+    lib = PKG / f"libimagescry_hip_{variant}.so" if variant else ABLATION_LIB if ablation else LIB
+    flags = [*FLAGS, "-DISC_ABLATION", *(f"-D{d}" for d in defines)] if ablation else FLAGS
     obj_dir.mkdir(exist_ok=True)
     sources = sorted(CSRC.glob("*.hip"))
     headers = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "imagescry_hip.h"]
@@ -68,4 +73,6 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, ablation="--ablation" in sys.argv))
+    _variant = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")), "")
+    _defines = tuple(a[2:] for a in sys.argv if a.startswith("-D"))
+    print(build(force="--force" in sys.argv, ablation="--ablation" in sys.argv, variant=_variant, defines=_defines))

@@ -379,6 +379,24 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     constexpr int WN = TNQ / 64;              // waves along the queries
     constexpr int WM = 8 / WN;                // waves along the bank rows
     constexpr int MB = TM / WM / 16;          // 16-row blocks per wave: 8 (TNQ 256) or 2 (TNQ 64)
+    // ASYMMETRIC row split of the 256-query filter loop.  The two waves of a SIMD share its matrix pipe, and the arbiter
+    // (priority, then age) serves one of them first: in-kernel stamps (scripts/stamp_search.py) show that wave done with
+    // its K step after ~1 940 cycles and idle at the barrier for the last third of the step, while its partner crawls on
+    // (2 890 cycles; without the static priority the roles swap, the picture stays).  So the favoured waves own MBHI of the
+    // tile's 16 row blocks and the others MBLO.  Sample launches (one tile per workgroup) and the 64-query shape stay
+    // symmetric.
+#ifndef ISC_ASYM_MBLO
+#define ISC_ASYM_MBLO 6
+#endif
+#ifndef ISC_ASYM_SPLIT_MBLO
+#define ISC_ASYM_SPLIT_MBLO 8
+#endif
+    constexpr bool NOSPLIT_FORM = DBG == 12 || DBG == 22;
+    constexpr int ASYM_LO = NOSPLIT_FORM ? ISC_ASYM_MBLO : DBG == 0 ? ISC_ASYM_SPLIT_MBLO : 8;
+    constexpr bool ASYM = TNQ == 256 && !SAMPLE && ASYM_LO != 8;
+    constexpr int MBLO = ASYM ? ASYM_LO : MB;        // row blocks of a wm = 0 wave
+    constexpr int MBHI = ASYM ? 2 * MB - MBLO : MB;  // ... of a wm = 1 wave
+    constexpr int MBMAX = MBHI > MBLO ? MBHI : MBLO;
     constexpr int B_TILE_BYTES = TNQ * 128;   // one K step of the query tile
     constexpr int NA = 4;                     // LDS-DMA instructions per thread per bank step (512 x 16 B x 4)
     constexpr int NB = B_TILE_BYTES / 8192;   // ... per query step: 4 or 1
@@ -439,7 +457,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     // wave + 8 i), so the wm = 1 wave of every SIMD never waits on a vector-memory issue slot and keeps the matrix
     // pipe fed while its partner is held up by the back-pressure of the L2 -> LDS path (+1 % at Q = 1024, +3.5 % at
     // Q = 256; DBG 12 = every wave issues its own share, the A/B reference)
-    constexpr bool SPLIT = TNQ == 256 && DBG != 12;
+    constexpr bool SPLIT = TNQ == 256 && DBG != 12 && DBG != 22;  // 22 = 12 + in-kernel stamps (ablation builds)
     // NT: the launch has ONE query tile, so every bank byte is read by exactly one workgroup, once: stream it with the
     // non-temporal policy (DBG 0 = the single-query-tile form of the 256-query shape, DBG 13 = of the 64-query shape)
     constexpr bool NT = (TNQ == 256 && DBG == 0) || DBG == 13;
@@ -506,12 +524,13 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     int foff[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) foff[kk] = frow * 128 + (((kk * 4 + fg) ^ fsw) << 4);
-    const int a_wave_off = wm * (TM / WM) * 128;
+    const int wave_row0 = ASYM ? (wm == 0 ? 0 : MBLO * 16) : wm * (TM / WM);  // first tile row of this wave
+    const int a_wave_off = wave_row0 * 128;
     const int b_wave_off = wn * 64 * 128;
 
-    f32x4 acc[MB][4];
+    f32x4 acc[MBMAX][4];
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int m = 0; m < MBMAX; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -525,7 +544,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     // The condition must be provably wave-uniform: s_setprio is a scalar instruction that ignores EXEC.
     // Not with SPLIT (DBG 0: only the older half issues the LDS-DMA there, and prioritising the other half on top of
     // that cost 4 %).
-    if constexpr (TNQ == 256 && DBG == 12) {
+    if constexpr (TNQ == 256 && (DBG == 12 || DBG == 22)) {
 #ifdef ISC_ABLATION
         if (!((nslots >> 18) & 1))
 #endif
@@ -536,18 +555,31 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     retire_for(0);
     __builtin_amdgcn_s_barrier();
 
+    // DBG 22 (ablation builds): s_memtime stamps split every K step of a wave into [reads + MFMA issue] [counted vmcnt
+    // wait] [barrier]; the sums go to seg_ent (unused: thresholds are +inf in this mode).  Read the SHARES, not the length.
+    unsigned long long st_compute = 0, st_vmwait = 0, st_barrier = 0, st_prev = 0;
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
     // The main loop exists in two instantiations (see "type B" below); the branch is taken once, outside the loop,
     // so neither version pays for the other's registers.
     auto main_loop = [&](auto stagger_tag) {
     constexpr bool STAGGER = decltype(stagger_tag)::value;
     int kt = 0, tile = 0;
+    if constexpr (DBG == 22) st_prev = stamp();
     for (int step = 0; step < total_steps; ++step) {
         if constexpr (TNQ == 256 && DBG != 7 && DBG != 17) {
-            // ---- 256-query shape.  One K step = 8 row blocks of 8 MFMAs (fp16).  Fragment reads run two row blocks
-            // ahead of the matrix cores (LDS returns in order: lgkmcnt(4) = "all but the newest two blocks"), and the
-            // eight LDS-DMA instructions of this iteration are issued one per row block, so their issue cost hides
-            // behind MFMAs instead of delaying the first one.  DMA stream order (the counted vmcnt relies on it):
-            // the query step first, then the bank step.
+            // ---- 256-query shape.  One K step = MBW row blocks of 8 MFMAs (fp16) for this wave.  Fragment reads run two
+            // row blocks ahead of the matrix cores (LDS returns in order: lgkmcnt(4) = "all but the newest two blocks"), and
+            // the eight LDS-DMA instructions of this iteration are spread over the row blocks, so their issue cost hides
+            // behind MFMAs instead of delaying the first one.  DMA stream order (the counted vmcnt relies on it): the query
+            // step first, then the bank step.
+            constexpr int MBW = STAGGER ? MBHI : MBLO;  // row blocks of this wave (the wm = 1 waves run the STAGGER copy)
+            static_assert(MBW >= 3 && MBW <= MBMAX, "row blocks per wave");
             const int sb = step + DB, sa = step + DA;
             const bool do_b = DBG != 2 && sb < total_steps;
             const bool do_a = DBG != 2 && sa < total_steps;
@@ -572,25 +604,40 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             ISC_DS_READ(ar[0][1], a_addr1, 0);
             ISC_DS_READ(ar[1][0], a_addr0, 2048);  // R2
             ISC_DS_READ(ar[1][1], a_addr1, 2048);
-#define ISC_DMA(j_)                                                                 \
-    if constexpr (SPLIT) {                                                          \
-        if constexpr (!STAGGER) { /* the wm = 0 loop: two pieces per row block (issuing the whole query step in  \
-                                     block 0 instead measured 1 % slower) */        \
-            if ((j_) < 4) {                                                         \
-                if (do_b) {                                                         \
-                    glds16(bsrc + 4096 * (2 * (j_)), bdst + 4096 * (2 * (j_)));     \
-                    glds16(bsrc + 4096 * (2 * (j_) + 1), bdst + 4096 * (2 * (j_) + 1)); \
-                }                                                                   \
-            } else if (do_a) {                                                      \
-                glds16_bank<NT>(asrc + 4096 * (2 * ((j_)-4)), adst + 4096 * (2 * ((j_)-4)));  \
-                glds16_bank<NT>(asrc + 4096 * (2 * ((j_)-4) + 1), adst + 4096 * (2 * ((j_)-4) + 1)); \
-            }                                                                       \
-        }                                                                           \
-    } else if ((j_) < 4) {                                                          \
-        if (do_b) glds16(bsrc + 8192 * (j_), bdst + 8192 * (j_));                   \
-    } else {                                                                        \
-        if (do_a) glds16_bank<NT>(asrc + 8192 * ((j_)-4), adst + 8192 * ((j_)-4));   \
-    }
+            // LDS-DMA piece j of this iteration (j < 4: the query step, then the bank step).  SPLIT: the wm = 0 loop issues two
+            // pieces per j, the wm = 1 loop none (issuing the whole query step in block 0 instead measured 1 % slower).
+            auto dma_piece = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (SPLIT) {
+                    if constexpr (!STAGGER) {
+                        if constexpr (j < 4) {
+                            if (do_b) {
+                                glds16(bsrc + 4096 * (2 * j), bdst + 4096 * (2 * j));
+                                glds16(bsrc + 4096 * (2 * j + 1), bdst + 4096 * (2 * j + 1));
+                            }
+                        } else if (do_a) {
+                            glds16_bank<NT>(asrc + 4096 * (2 * (j - 4)), adst + 4096 * (2 * (j - 4)));
+                            glds16_bank<NT>(asrc + 4096 * (2 * (j - 4) + 1), adst + 4096 * (2 * (j - 4) + 1));
+                        }
+                    }
+                } else if constexpr (j < 4) {
+                    if (do_b) glds16(bsrc + 8192 * j, bdst + 8192 * j);
+                } else {
+                    if (do_a) glds16_bank<NT>(asrc + 8192 * (j - 4), adst + 8192 * (j - 4));
+                }
+            };
+            // the eight pieces in stream order over the MBW row blocks: the first 8 - MBW blocks take two (MBW < 8), blocks
+            // past the eighth none (MBW > 8)
+            auto dma_at = [&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int extra = MBW < 8 ? 8 - MBW : 0;
+                if constexpr (m < extra) {
+                    dma_piece(std::integral_constant<int, 2 * m>{});
+                    dma_piece(std::integral_constant<int, 2 * m + 1>{});
+                } else if constexpr (m + extra < 8) {
+                    dma_piece(std::integral_constant<int, m + extra>{});
+                }
+            };
 #define ISC_MFMA_HALF(a_, b_, m_)                                                                         \
     if constexpr (DBG != 3) Mma<T>::half(a_, b_, acc[m_]);                                                 \
     else acc[m_][0][0] += __uint_as_float((a_)[0] ^ (b_)[1][1] ^ (b_)[2][2]);
@@ -606,64 +653,61 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                 ISC_MFMA_HALF(ar[0][0], b0, 0)
                 ISC_DS_READ(ar[2][0], a_addr0, 4096);  // R3
                 ISC_DS_READ(ar[2][1], a_addr1, 4096);
-                ISC_DMA(0)
+                dma_at(std::integral_constant<int, 0>{});
                 asm volatile("s_waitcnt lgkmcnt(2)"
                              : "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]), "+v"(ar[0][1]), "+v"(ar[1][0]),
                                "+v"(ar[1][1]));
                 __builtin_amdgcn_sched_barrier(0);
                 ISC_MFMA_HALF(ar[0][1], b1, 0)
-#define ISC_ROW_BLOCK_B(m_, cur_, nxt_, nn_, wait_)                                                        \
-    ISC_MFMA_HALF(ar[cur_][0], b0, m_)                                                                     \
-    if constexpr ((m_) + 2 < 8) {                                                                          \
-        ISC_DS_READ(ar[nn_][0], a_addr0, ((m_) + 2) * 2048);                                               \
-        ISC_DS_READ(ar[nn_][1], a_addr1, ((m_) + 2) * 2048);                                               \
-    }                                                                                                      \
-    ISC_DMA(m_)                                                                                            \
-    if constexpr ((m_) + 1 < 8) {                                                                          \
-        asm volatile("s_waitcnt lgkmcnt(" wait_ ")" : "+v"(ar[nxt_][0]), "+v"(ar[nxt_][1]), "+v"(ar[cur_][1])); \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-    }                                                                                                      \
-    ISC_MFMA_HALF(ar[cur_][1], b1, m_)
-                ISC_ROW_BLOCK_B(1, 1, 2, 0, "2")
-                ISC_ROW_BLOCK_B(2, 2, 0, 1, "2")
-                ISC_ROW_BLOCK_B(3, 0, 1, 2, "2")
-                ISC_ROW_BLOCK_B(4, 1, 2, 0, "2")
-                ISC_ROW_BLOCK_B(5, 2, 0, 1, "2")
-                ISC_ROW_BLOCK_B(6, 0, 1, 2, "0")
-                ISC_ROW_BLOCK_B(7, 1, 2, 0, "0")
-#undef ISC_ROW_BLOCK_B
+                auto blocks = [&](auto self, auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    constexpr int cur = m % 3, nxt = (m + 1) % 3, nn = (m + 2) % 3;
+                    ISC_MFMA_HALF(ar[cur][0], b0, m)
+                    if constexpr (m + 2 < MBW) {
+                        ISC_DS_READ(ar[nn][0], a_addr0, (m + 2) * 2048);
+                        ISC_DS_READ(ar[nn][1], a_addr1, (m + 2) * 2048);
+                    }
+                    dma_at(mc);
+                    if constexpr (m + 1 < MBW) {
+                        asm volatile("s_waitcnt lgkmcnt(%3)"
+                                     : "+v"(ar[nxt][0]), "+v"(ar[nxt][1]), "+v"(ar[cur][1])
+                                     : "i"(m + 2 < MBW ? 2 : 0));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    ISC_MFMA_HALF(ar[cur][1], b1, m)
+                    if constexpr (m + 1 < MBW) self(self, std::integral_constant<int, m + 1>{});
+                };
+                blocks(blocks, std::integral_constant<int, 1>{});
             } else {
-            // ---- type A.  row block 0: its two halves arrive separately
-            ISC_DS_READ(ar[2][0], a_addr0, 4096);  // R3
-            ISC_DS_READ(ar[2][1], a_addr1, 4096);
-            asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(ar[0][0]));
-            __builtin_amdgcn_sched_barrier(0);
-            ISC_DMA(0)
-            ISC_MFMA_HALF(ar[0][0], b0, 0)
-            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]), "+v"(ar[0][1]));
-            __builtin_amdgcn_sched_barrier(0);
-            ISC_MFMA_HALF(ar[0][1], b1, 0)
-#define ISC_ROW_BLOCK(m_, cur_, nxt_, wait_)                                                   \
-    if constexpr ((m_) + 2 < 8) {                                                              \
-        ISC_DS_READ(ar[nxt_][0], a_addr0, ((m_) + 2) * 2048);                                  \
-        ISC_DS_READ(ar[nxt_][1], a_addr1, ((m_) + 2) * 2048);                                  \
-    }                                                                                          \
-    asm volatile("s_waitcnt lgkmcnt(" wait_ ")" : "+v"(ar[cur_][0]), "+v"(ar[cur_][1]));       \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    ISC_DMA(m_)                                                                                \
-    ISC_MFMA_HALF(ar[cur_][0], b0, m_)                                                         \
-    ISC_MFMA_HALF(ar[cur_][1], b1, m_)
-            ISC_ROW_BLOCK(1, 1, 0, "4")
-            ISC_ROW_BLOCK(2, 2, 1, "4")
-            ISC_ROW_BLOCK(3, 0, 2, "4")
-            ISC_ROW_BLOCK(4, 1, 0, "4")
-            ISC_ROW_BLOCK(5, 2, 1, "4")
-            ISC_ROW_BLOCK(6, 0, 2, "2")
-            ISC_ROW_BLOCK(7, 1, 0, "0")
+                // ---- type A.  row block 0: its two halves arrive separately
+                ISC_DS_READ(ar[2][0], a_addr0, 4096);  // R3
+                ISC_DS_READ(ar[2][1], a_addr1, 4096);
+                asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(ar[0][0]));
+                __builtin_amdgcn_sched_barrier(0);
+                dma_at(std::integral_constant<int, 0>{});
+                ISC_MFMA_HALF(ar[0][0], b0, 0)
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]), "+v"(ar[0][1]));
+                __builtin_amdgcn_sched_barrier(0);
+                ISC_MFMA_HALF(ar[0][1], b1, 0)
+                auto blocks = [&](auto self, auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    constexpr int cur = m % 3, nn = (m + 2) % 3;
+                    if constexpr (m + 2 < MBW) {
+                        ISC_DS_READ(ar[nn][0], a_addr0, (m + 2) * 2048);
+                        ISC_DS_READ(ar[nn][1], a_addr1, (m + 2) * 2048);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(%2)"
+                                 : "+v"(ar[cur][0]), "+v"(ar[cur][1])
+                                 : "i"(m + 2 < MBW ? 4 : m + 1 < MBW ? 2 : 0));
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_at(mc);
+                    ISC_MFMA_HALF(ar[cur][0], b0, m)
+                    ISC_MFMA_HALF(ar[cur][1], b1, m)
+                    if constexpr (m + 1 < MBW) self(self, std::integral_constant<int, m + 1>{});
+                };
+                blocks(blocks, std::integral_constant<int, 1>{});
             }
-#undef ISC_ROW_BLOCK
 #undef ISC_MFMA_HALF
-#undef ISC_DMA
         } else {
         issue_iter(step);
 
@@ -735,12 +779,13 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             // filter score is <= the kp-th carried one either way) -- while ">=" let every row of a zero query, or every
             // copy of a duplicated row, through and overflowed the buffers.
             kt = 0;
-            const int64_t trow0 = r0 + (int64_t)(tile_begin + tile) * TM + wm * (TM / WM) + fg * 4;
+            constexpr int MBE = STAGGER ? MBHI : MBLO;  // this wave's row blocks (MB when the split is symmetric)
+            const int64_t trow0 = r0 + (int64_t)(tile_begin + tile) * TM + wave_row0 + fg * 4;
             // rows past the end of the level exist only in its last tile: they become -inf there, once, instead of
             // being tested per element
             if (r0 + (int64_t)(tile_begin + tile + 1) * TM > r1) {
 #pragma unroll
-                for (int m = 0; m < MB; ++m)
+                for (int m = 0; m < MBE; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (trow0 + m * 16 + r >= r1) {
@@ -754,16 +799,16 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             // sample's threshold, 86 % of the first level's tiles trip: the scan was 17 % of that level).
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                float bm[MB];
+                float bm[MBE];
                 float mx = -INFINITY;
 #pragma unroll
-                for (int m = 0; m < MB; ++m) {
+                for (int m = 0; m < MBE; ++m) {
                     bm[m] = fmaxf(fmaxf(acc[m][n][0], acc[m][n][1]), fmaxf(acc[m][n][2], acc[m][n][3]));
                     mx = fmaxf(mx, bm[m]);
                 }
                 if (__ballot(mx > thr[n]) != 0ull) {
 #pragma unroll
-                    for (int m = 0; m < MB; ++m) {
+                    for (int m = 0; m < MBE; ++m) {
                         if (__ballot(bm[m] > thr[n]) == 0ull) continue;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -777,7 +822,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                 }
             }
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
+            for (int m = 0; m < MBE; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
             ++tile;
@@ -786,8 +831,30 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 
         // retire this wave's DMA for step + 1; the barrier then publishes every wave's pieces and guarantees nobody
         // still reads the slots refilled next iteration
+        if constexpr (DBG == 22) {
+            const unsigned long long tb = stamp();
+            retire_for(step + 1);
+            const unsigned long long tc = stamp();
+            __builtin_amdgcn_s_barrier();
+            const unsigned long long td = stamp();
+            st_compute += tb - st_prev;
+            st_vmwait += tc - tb;
+            st_barrier += td - tc;
+            st_prev = td;
+        } else {
         retire_for(step + 1);
         __builtin_amdgcn_s_barrier();
+        }
+    }
+    if constexpr (DBG == 22) {
+        if (lane == 0) {
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(seg_ent) +
+                                      ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+            dbg[0] = st_compute;
+            dbg[1] = st_vmwait;
+            dbg[2] = st_barrier;
+            dbg[3] = (unsigned long long)total_steps;
+        }
     }
     };
     if (TNQ == 256 && DBG != 11 && __builtin_amdgcn_readfirstlane(wm) == 1) main_loop(std::true_type{});  // DBG 12 relies on this split
@@ -1499,6 +1566,7 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const Filt
         case 11: ISC_LAUNCH_FILTER(11, false); break;
         case 15: ISC_LAUNCH_FILTER(15, false); break;
         case 17: ISC_LAUNCH_FILTER(17, false); break;
+        case 22: ISC_LAUNCH_FILTER(22, false); break;
 #endif
         case 12: ISC_LAUNCH_FILTER(12, false); break;
         default:
