@@ -241,17 +241,18 @@ def measured_traffic(config: dict) -> tuple[float | None, str | None, bool]:
     return None, None, False
 
 
-def measured_encode_traffic(batch: int) -> tuple[float | None, str | None]:
-    """HBM bytes per `k_conv_f32` launch of the ResNet-50 encode step from the newest committed PMC summary for this batch
-    size (profiles/*_encode_traffic.json, scripts/pmc_encode.sh + scripts/summarize_encode_traffic.py)."""
-    for f in sorted((ROOT / "profiles").glob("*_encode_traffic.json"), reverse=True):
+def measured_encoder_traffic(model: str, batch: int) -> tuple[float | None, str | None, float | None]:
+    """L2 <-> fabric bytes per `k_conv_f32` launch of one encoder's predict_step from the newest committed PMC summary of
+    the kernel bench.py times (profiles/*_<model>_traffic.json: scripts/pmc_encoder.sh + scripts/summarize_encoder_traffic.py;
+    the round-1/2 `*_encode_traffic.json` files were taken on kernels that are no longer built and are not read)."""
+    for f in sorted((ROOT / "profiles").glob(f"*_{model}_traffic.json"), reverse=True):
         try:
             t = json.loads(f.read_text())
         except (OSError, ValueError):
             continue
-        if t.get("config", {}).get("batch_per_gpu") == batch:
-            return float(t["hbm_bytes_per_launch"]), f"profiles/{f.name}"
-    return None, None
+        if t.get("config", {}).get("batch_per_gpu") == batch and t.get("config", {}).get("model") == model:
+            return float(t["hbm_bytes_per_launch"]), f"profiles/{f.name}", t.get("traffic_over_algorithmic")
+    return None, None, None
 
 
 def measured_vit_traffic(batch: int) -> tuple[float | None, str | None, float | None]:
@@ -548,7 +549,7 @@ def bench_encode(args: argparse.Namespace, rank: int, world: int, device: torch.
     flops = float(resnet50.conv_flops(b, 224, 224))
     tflops = flops * steps / (kernel_ms / 1e3) / 1e12
     ranks = world if collective_timing else 1
-    enc_traffic, enc_traffic_src = measured_encode_traffic(b)
+    enc_traffic, enc_traffic_src, enc_ratio = measured_encoder_traffic("resnet50", b)
     return {
         "metric": "images/s encode",
         "value": round(b * ranks * steps / seconds, 1),
@@ -567,10 +568,12 @@ def bench_encode(args: argparse.Namespace, rank: int, world: int, device: torch.
             "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
             "traffic": enc_traffic,
             "traffic_source": enc_traffic_src,
+            "traffic_over_algorithmic": enc_ratio,
             "launches_per_step": launches / steps,
             "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
             "kernel_ms_per_step": round(kernel_ms / steps, 3),
             "algorithmic_flops_per_step": flops,
+            "algorithmic_bytes_per_step": float(resnet50.conv_bytes(b, 224, 224)),
         },
         "_model": model, "_images": images,
     }
@@ -639,6 +642,7 @@ def bench_encode_efficientnet(args: argparse.Namespace, device: torch.device, st
     _lib.timing_enable(False)
     flops = float(efficientnet.conv_flops("s", b, 224, 224))
     tflops = flops * steps / (kernel_ms / 1e3) / 1e12
+    eff_traffic, eff_traffic_src, eff_ratio = measured_encoder_traffic("efficientnet_s", b)
     return {
         "metric": "images/s encode",
         "value": round(b * steps / seconds, 1),
@@ -654,7 +658,10 @@ def bench_encode_efficientnet(args: argparse.Namespace, device: torch.device, st
             "peak": MFMA_F32_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
-            "traffic": None,
+            "traffic": eff_traffic,
+            "traffic_source": eff_traffic_src,
+            "traffic_over_algorithmic": eff_ratio,
+            "algorithmic_bytes_per_step": float(efficientnet.conv_bytes("s", b, 224, 224)),
             "launches_per_step": launches / steps,
             "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
             "kernel_ms_per_step": round(kernel_ms / steps, 3),

@@ -131,6 +131,37 @@ def conv_flops(size: str, batch: int, height: int, width: int) -> int:
     return total
 
 
+def conv_bytes(size: str, batch: int, height: int, width: int) -> int:
+    """Algorithmic HBM bytes of the `k_conv_f32` launches of one forward pass: every dense convolution reads its float32
+    input once, its residual once where the block has one (stride 1, cin == cout), its weights once, writes its output
+    once.  Depthwise sweeps and SE gates are other kernels and not counted.  Compared with `roofline.traffic`."""
+    def down(n: int, s: int) -> int:
+        return (n + s - 1) // s
+
+    h, w = down(height, 2), down(width, 2)
+    c0 = STAGES[size][0][4]
+    total = 4 * (batch * height * width * 4 + batch * h * w * c0 + c0 * 27)
+    last = c0
+    for blocks in block_specs(size):
+        for b in blocks:
+            h2, w2 = down(h, b.stride), down(w, b.stride)
+            k2 = b.kernel * b.kernel
+            pin, pout = batch * h * w, batch * h2 * w2
+            res = pout * b.cout if (b.stride == 1 and b.cin == b.cout) else 0
+            if b.kind == "fused":
+                if b.expand == 1:
+                    total += 4 * (pin * b.cin + pout * b.cout + res + b.cout * b.cin * k2)
+                else:
+                    total += 4 * (pin * b.cin + pout * b.expanded + b.expanded * b.cin * k2)
+                    total += 4 * (pout * b.expanded + pout * b.cout + res + b.cout * b.expanded)
+            else:
+                total += 4 * (pin * b.cin + pin * b.expanded + b.expanded * b.cin)  # expand 1x1
+                total += 4 * (pout * b.expanded + pout * b.cout + res + b.cout * b.expanded)  # project
+            h, w, last = h2, w2, b.cout
+    total += 4 * (batch * h * w * last + batch * h * w * LAST_CHANNELS + LAST_CHANNELS * last)  # head 1x1
+    return total
+
+
 # ------------------------------------------------------------------------------------------- parameters
 def make_state_dict(size: str = "s", *, seed: int = 0, randomize_bn: bool = False) -> dict[str, Tensor]:
     """Seeded random parameters with torchvision's names and init (conv: kaiming-normal fan_out; BatchNorm identity,

@@ -166,3 +166,29 @@ def conv_flops(batch: int, height: int, width: int, embedding_dim: int = 768) ->
             h, w = h2, w2
     total += 2 * batch * inplanes * embedding_dim
     return total
+
+
+def conv_bytes(batch: int, height: int, width: int, embedding_dim: int = 768) -> int:
+    """Algorithmic HBM bytes of the `k_conv_f32` launches of one forward pass: every convolution reads its float32 input
+    map once (the stem its 4-channel NHWC input), its residual once where it has one, its weights once, and writes its
+    output once.  What `roofline.traffic` is compared with (the measured L2 <-> fabric bytes re-read 3 x 3 inputs)."""
+    def out(n: int, k: int, s: int, p: int) -> int:
+        return (n + 2 * p - k) // s + 1
+
+    h, w = out(height, 7, 2, 3), out(width, 7, 2, 3)
+    total = 4 * (batch * height * width * 4 + batch * h * w * 64 + 64 * 7 * 7 * 4)
+    h, w = out(h, 3, 2, 1), out(w, 3, 2, 1)
+    inplanes = 64
+    for planes, nblocks, stride in STAGES:
+        for bi in range(nblocks):
+            s = stride if bi == 0 else 1
+            h2, w2 = out(h, 3, s, 1), out(w, 3, s, 1)
+            pin, pout = batch * h * w, batch * h2 * w2
+            total += 4 * (pin * inplanes + pin * planes + planes * inplanes)  # conv1
+            total += 4 * (pin * planes + pout * planes + planes * planes * 9)  # conv2
+            total += 4 * (pout * planes + 2 * pout * planes * EXPANSION + planes * EXPANSION * planes)  # conv3 + residual
+            if bi == 0 and (s != 1 or inplanes != planes * EXPANSION):  # downsample reads the strided input pixels
+                total += 4 * (pout * inplanes + pout * planes * EXPANSION + planes * EXPANSION * inplanes)
+            inplanes = planes * EXPANSION
+            h, w = h2, w2
+    return total
