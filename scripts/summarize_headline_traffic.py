@@ -20,29 +20,37 @@ tag = sys.argv[1]
 src = ROOT / "gpurun_out" / f"pmc_headline_{tag}"
 
 
-def total(sub: str, counter: str) -> tuple[float, int]:
+def total(sub: str, counter: str) -> tuple[float, int, int]:
+    """(sum of the counter over every k_dots_filter launch, those launches, searches profiled).  A search is one k_prep
+    launch; its k_dots_filter launches include the redo launches behind k_final, which normally exit at once and move no
+    bytes -- so the bytes are divided by SEARCHES and by the bench line's `launches_per_step` (the launches that stream)."""
     files = sorted(glob.glob(str(src / sub / "*/*counter_collection.csv")), key=lambda f: Path(f).stat().st_mtime, reverse=True)
-    s, n = 0.0, 0
+    s, n, searches = 0.0, 0, 0
     for r in csv.DictReader(open(files[0])):
-        if "k_dots_filter" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if r["Counter_Name"] != counter:
+            continue
+        if "k_dots_filter" in r["Kernel_Name"]:
             s += float(r["Counter_Value"])
             n += 1
-    return s, n
+        elif "k_prep" in r["Kernel_Name"]:
+            searches += 1
+    return s, n, searches
 
 
 bench = json.loads((src / "bench_fetch.json").read_text().strip().splitlines()[-1])
-fetch, n_f = total("fetch", "FETCH_SIZE")
-write, n_w = total("write", "WRITE_SIZE")
-assert n_f == n_w and n_f > 0
-read_b = fetch * 1024 * 2 / n_f
-write_b = write * 1024 / n_w
+fetch, n_f, s_f = total("fetch", "FETCH_SIZE")
+write, n_w, s_w = total("write", "WRITE_SIZE")
+assert n_f == n_w and n_f > 0 and s_f == s_w and s_f > 0
 lps = bench["roofline"]["launches_per_step"]
+read_b = fetch * 1024 * 2 / s_f / lps
+write_b = write * 1024 / s_w / lps
 algo = bench["roofline"]["algorithmic_bytes_per_step"] / lps
 out = {
     "tag": tag,
     "config": bench["config"],
     "kernel": "k_dots_filter",
     "launches_profiled": n_f,
+    "searches_profiled": s_f,
     "hbm_read_bytes_per_launch": read_b,
     "hbm_write_bytes_per_launch": write_b,
     "hbm_bytes_per_launch": read_b + write_b,

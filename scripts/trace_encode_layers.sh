@@ -41,7 +41,7 @@ for li, (planes, nb, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2),
         layers.append((f"l{li}.{bi}.conv3 1x1+res", px_out, planes, planes * 4, px_out * planes * 4, px_out * planes * 16, px_out * planes * 16))
         inpl = planes * 4
         h = h2
-layers.append(("fc 2048->768", B, 2048, 768, B * 2048 * 4, B * 768 * 4, 0))
+# (the projection head is no longer a k_conv_f32 launch: k_pool_linear_l2norm, reported below)
 import os
 f = max(glob.glob("gpurun_out/prof_enc/*/*kernel_trace.csv"), key=os.path.getmtime)
 rows = [r for r in csv.DictReader(open(f)) if "k_conv_f32" in r["Kernel_Name"] or "k_conv1x1_f32_stream" in r["Kernel_Name"]]
@@ -71,4 +71,11 @@ for (name, m, k, nn, ib, ob, rb), r in zip(layers, last):
 print(f"total conv {tot_t:.0f} us, {tot_f/tot_t/1e6:.1f} TFLOP/s = {tot_f/tot_t/1e6/157.3:.3f} of the f32 MFMA peak")
 for k2, (us, fl) in agg.items():
     print(f"  {k2:12s} {us:8.0f} us  {fl/us/1e6:6.1f} TFLOP/s")
+others = {}
+for r in csv.DictReader(open(f)):
+    for kn in ("k_pool_linear_l2norm", "k_maxpool_nhwc", "k_normalize_nhwc4", "k_stats_partial", "k_stats_final"):
+        if kn in r["Kernel_Name"]:
+            others.setdefault(kn, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for kn, v in others.items():
+    print(f"  {kn:24s} {sum(v)/len(v):8.1f} us per launch ({len(v)} launches in the trace)")
 PY
