@@ -374,8 +374,14 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                                                           Cand* __restrict__ qlist, int kp, int nslots,
                                                           int32_t* __restrict__ qflag, int32_t* __restrict__ status,
                                                           const int32_t* __restrict__ active) {
-    // redo launches (k_final2's feeder): `active` counts the listed query slots -- normally zero, and the launch ends here
-    if (active != nullptr && *active <= (int)blockIdx.y * TNQ) return;
+    // DBG 20 / 32 / 33 are the REDO instantiations of 0 / 12 / 13 (k_final2's feeder: the whole bank against the fixed
+    // thresholds of the listed queries).  They are kernels of their own so that a profile lists them apart from the
+    // search's streaming launches; `active` counts the listed query slots -- normally zero, and the launch ends here.
+    constexpr bool REDO = DBG == 20 || DBG == 32 || DBG == 33;
+    constexpr int MODE = DBG == 20 ? 0 : DBG == 32 ? 12 : DBG == 33 ? 13 : DBG;
+    if constexpr (REDO) {
+        if (*active <= (int)blockIdx.y * TNQ) return;
+    }
     constexpr int WN = TNQ / 64;              // waves along the queries
     constexpr int WM = 8 / WN;                // waves along the bank rows
     constexpr int MB = TM / WM / 16;          // 16-row blocks per wave: 8 (TNQ 256) or 2 (TNQ 64)
@@ -391,8 +397,8 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 #ifndef ISC_ASYM_SPLIT_MBLO
 #define ISC_ASYM_SPLIT_MBLO 8
 #endif
-    constexpr bool NOSPLIT_FORM = DBG == 12 || DBG == 22;
-    constexpr int ASYM_LO = NOSPLIT_FORM ? ISC_ASYM_MBLO : DBG == 0 ? ISC_ASYM_SPLIT_MBLO : 8;
+    constexpr bool NOSPLIT_FORM = MODE == 12 || MODE == 22;
+    constexpr int ASYM_LO = NOSPLIT_FORM ? ISC_ASYM_MBLO : MODE == 0 ? ISC_ASYM_SPLIT_MBLO : 8;
     constexpr bool ASYM = TNQ == 256 && !SAMPLE && ASYM_LO != 8;
     constexpr int MBLO = ASYM ? ASYM_LO : MB;        // row blocks of a wm = 0 wave
     constexpr int MBHI = ASYM ? 2 * MB - MBLO : MB;  // ... of a wm = 1 wave
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         thr[n] = tau[q0 + wn * 64 + n * 16 + frow];
-        if ((DBG != 0 && DBG < 11) || DBG >= 15) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
+        if ((MODE != 0 && MODE < 11) || MODE >= 15) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
 #ifdef ISC_ABLATION
         if (!SAMPLE && g_abl_thr_inf) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ISC_THR_INF: the price of scanning + the tail
 #endif
@@ -456,11 +462,11 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     // SPLIT (256-query shape): only the wm = 0 waves issue LDS-DMA, twice as many each (pieces wave + 4 i instead of
     // wave + 8 i), so the wm = 1 wave of every SIMD never waits on a vector-memory issue slot and keeps the matrix
     // pipe fed while its partner is held up by the back-pressure of the L2 -> LDS path (+1 % at Q = 1024, +3.5 % at
-    // Q = 256; DBG 12 = every wave issues its own share, the A/B reference)
-    constexpr bool SPLIT = TNQ == 256 && DBG != 12 && DBG != 22;  // 22 = 12 + in-kernel stamps (ablation builds)
+    // Q = 256; MODE 12 = every wave issues its own share, the A/B reference)
+    constexpr bool SPLIT = TNQ == 256 && MODE != 12 && MODE != 22;  // 22 = 12 + in-kernel stamps (ablation builds)
     // NT: the launch has ONE query tile, so every bank byte is read by exactly one workgroup, once: stream it with the
-    // non-temporal policy (DBG 0 = the single-query-tile form of the 256-query shape, DBG 13 = of the 64-query shape)
-    constexpr bool NT = (TNQ == 256 && DBG == 0) || DBG == 13;
+    // non-temporal policy (MODE 0 = the single-query-tile form of the 256-query shape, MODE 13 = of the 64-query shape)
+    constexpr bool NT = (TNQ == 256 && MODE == 0) || MODE == 13;
     auto issue_a = [&](int step) {
         const unsigned char* src = a_stream + (int64_t)step * A_TILE_BYTES;
         unsigned char* dst = lds_a + (step % A_ST) * A_TILE_BYTES + wave_dst;
@@ -489,18 +495,18 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     };
     // what iteration `it` issues (it < 0: prologue): first the query step, then the bank step
     auto issue_iter = [&](int it) {
-        if ((DBG == 2 || DBG == 7) && it >= 0) return;
+        if ((MODE == 2 || MODE == 7) && it >= 0) return;
         const int sb = it + DB, sa = it + DA;
         if (sb >= 0 && sb < total_steps) issue_b(sb);
         if (sa >= 0 && sa < total_steps) issue_a(sa);
     };
     // after iteration `next - 1` has issued: retire everything step `next` needs, leave the younger DMA in flight
     auto retire_for = [&](int next) {
-        if (DBG == 2 || DBG == 7) {
+        if (MODE == 2 || MODE == 7) {
             wait_vmcnt<0>();
             return;
         }
-        if (DBG == 15) return;  // ablation: the DMA is issued but never waited for (stale operands, wrong results)
+        if (MODE == 15) return;  // ablation: the DMA is issued but never waited for (stale operands, wrong results)
         if (TNQ == 256) {  // stream order ... B(next) A(next + 1): only A(next + 1) may stay in flight
             if constexpr (SPLIT) {
                 if (wm == 0) {
@@ -542,9 +548,9 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     // (MI355X_MICROARCH.md, "Two waves per SIMD" item 4); one s_setprio before the loop, no flips inside.  +1.0 % at
     // Q = 1024 (scripts/ab_headline.sh, three interleaved rounds: 13.71 -> 13.57 ms); per-cluster flips lost 5 % in round 1.
     // The condition must be provably wave-uniform: s_setprio is a scalar instruction that ignores EXEC.
-    // Not with SPLIT (DBG 0: only the older half issues the LDS-DMA there, and prioritising the other half on top of
+    // Not with SPLIT (MODE 0: only the older half issues the LDS-DMA there, and prioritising the other half on top of
     // that cost 4 %).
-    if constexpr (TNQ == 256 && (DBG == 12 || DBG == 22)) {
+    if constexpr (TNQ == 256 && (MODE == 12 || MODE == 22)) {
 #ifdef ISC_ABLATION
         if (!((nslots >> 18) & 1))
 #endif
@@ -555,7 +561,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     retire_for(0);
     __builtin_amdgcn_s_barrier();
 
-    // DBG 22 (ablation builds): s_memtime stamps split every K step of a wave into [reads + MFMA issue] [counted vmcnt
+    // MODE 22 (ablation builds): s_memtime stamps split every K step of a wave into [reads + MFMA issue] [counted vmcnt
     // wait] [barrier]; the sums go to seg_ent (unused: thresholds are +inf in this mode).  Read the SHARES, not the length.
     unsigned long long st_compute = 0, st_vmwait = 0, st_barrier = 0, st_prev = 0;
     auto stamp = [&]() -> unsigned long long {
@@ -570,9 +576,9 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     auto main_loop = [&](auto stagger_tag) {
     constexpr bool STAGGER = decltype(stagger_tag)::value;
     int kt = 0, tile = 0;
-    if constexpr (DBG == 22) st_prev = stamp();
+    if constexpr (MODE == 22) st_prev = stamp();
     for (int step = 0; step < total_steps; ++step) {
-        if constexpr (TNQ == 256 && DBG != 7 && DBG != 17) {
+        if constexpr (TNQ == 256 && MODE != 7 && MODE != 17) {
             // ---- 256-query shape.  One K step = MBW row blocks of 8 MFMAs (fp16) for this wave.  Fragment reads run two
             // row blocks ahead of the matrix cores (LDS returns in order: lgkmcnt(4) = "all but the newest two blocks"), and
             // the eight LDS-DMA instructions of this iteration are spread over the row blocks, so their issue cost hides
@@ -581,8 +587,8 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             constexpr int MBW = STAGGER ? MBHI : MBLO;  // row blocks of this wave (the wm = 1 waves run the STAGGER copy)
             static_assert(MBW >= 3 && MBW <= MBMAX, "row blocks per wave");
             const int sb = step + DB, sa = step + DA;
-            const bool do_b = DBG != 2 && sb < total_steps;
-            const bool do_a = DBG != 2 && sa < total_steps;
+            const bool do_b = MODE != 2 && sb < total_steps;
+            const bool do_a = MODE != 2 && sa < total_steps;
             const unsigned char* bsrc = b_stream + (int64_t)(sb % ksteps) * B_TILE_BYTES;
             unsigned char* bdst = lds_b + (sb % B_ST) * B_TILE_BYTES + wave_dst;
             const unsigned char* asrc = a_stream + (int64_t)sa * A_TILE_BYTES;
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                 }
             };
 #define ISC_MFMA_HALF(a_, b_, m_)                                                                         \
-    if constexpr (DBG != 3) Mma<T>::half(a_, b_, acc[m_]);                                                 \
+    if constexpr (MODE != 3) Mma<T>::half(a_, b_, acc[m_]);                                                 \
     else acc[m_][0][0] += __uint_as_float((a_)[0] ^ (b_)[1][1] ^ (b_)[2][2]);
             // The two waves that share a SIMD (waves w and w + 4, i.e. wm = 0 and wm = 1) run the same program between
             // the same barriers; left alone they reach their read / wait / DMA-issue instructions together and the
@@ -719,7 +725,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             const unsigned a_addr0 = a_addr + foff[0], a_addr1 = a_addr + foff[1];
             const unsigned b_addr0 = b_addr + foff[0], b_addr1 = b_addr + foff[1];
             u32x4 bq[2][4], ar[2][2];
-            if constexpr (DBG == 7 || DBG == 17) {  // no LDS traffic: feed the matrix cores from whatever the registers hold
+            if constexpr (MODE == 7 || MODE == 17) {  // no LDS traffic: feed the matrix cores from whatever the registers hold
 #pragma unroll
                 for (int i = 0; i < 8; ++i) bq[i >> 2][i & 3] = u32x4{(unsigned)step, 1u, 2u, (unsigned)lane};
                 ar[0][0] = ar[0][1] = ar[1][0] = ar[1][1] = u32x4{(unsigned)lane, 3u, (unsigned)step, 5u};
@@ -751,7 +757,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
         else                                                                                                         \
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[cur_][0]), "+v"(ar[cur_][1]));                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if constexpr (DBG != 3)                                                                                      \
+        if constexpr (MODE != 3)                                                                                      \
             Mma<T>::row(ar[cur_][0], ar[cur_][1], bq, acc[m_]);                                                      \
         else                                                                                                         \
             acc[m_][0][0] += __uint_as_float(ar[cur_][0][0] ^ ar[cur_][1][1] ^ bq[0][1][0] ^ bq[1][2][1]);           \
@@ -831,7 +837,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 
         // retire this wave's DMA for step + 1; the barrier then publishes every wave's pieces and guarantees nobody
         // still reads the slots refilled next iteration
-        if constexpr (DBG == 22) {
+        if constexpr (MODE == 22) {
             const unsigned long long tb = stamp();
             retire_for(step + 1);
             const unsigned long long tc = stamp();
@@ -846,7 +852,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
         __builtin_amdgcn_s_barrier();
         }
     }
-    if constexpr (DBG == 22) {
+    if constexpr (MODE == 22) {
         if (lane == 0) {
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(seg_ent) +
                                       ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 4;
@@ -857,7 +863,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
         }
     }
     };
-    if (TNQ == 256 && DBG != 11 && __builtin_amdgcn_readfirstlane(wm) == 1) main_loop(std::true_type{});  // DBG 12 relies on this split
+    if (TNQ == 256 && MODE != 11 && __builtin_amdgcn_readfirstlane(wm) == 1) main_loop(std::true_type{});  // MODE 12 relies on this split
     else main_loop(std::false_type{});
 
 #ifdef ISC_ABLATION  // timing aids (wrong results): nslots bit 16 = stop after the main loop, bit 17 = stop before the tail
@@ -1541,6 +1547,13 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const Filt
             ISC_LAUNCH_FILTER(12, true);
         }
 #endif
+        return;
+    }
+    if (io.active) {  // the redo of unproven queries: its own instantiations (never an ablation variant), see the kernel
+        if (TNQ == 256 && p.qtiles > 1) ISC_LAUNCH_FILTER(32, false);
+        else if constexpr (TNQ == 256) ISC_LAUNCH_FILTER(20, false);
+        else if (p.qtiles == 1) ISC_LAUNCH_FILTER(33, false);
+        else ISC_LAUNCH_FILTER(32, false);
         return;
     }
     // SPLIT (DBG 0) pays where a chunk has ONE query tile (Q <= 256).  With several query-tile workgroups streaming the

@@ -102,9 +102,12 @@ def test_production_library_holds_no_ablation_kernels(library: ctypes.CDLL) -> N
     out = subprocess.run([nm, str(_lib.LIB_PATH)], check=True, capture_output=True, text=True).stdout
     # mangled template arguments: I <dtype: DF16_ | f> Li<tile>E Li<staging variant>E Lb<sample>E
     variants = sorted(set(re.findall(r"13k_dots_filterI(DF16_|f)Li(\d+)ELi(\d+)ELb([01])E", out)))
+    # ... plus the REDO instantiations (20 / 32 / 33 = the redo forms of 0 / 12 / 13: the same loops against the fixed
+    # thresholds of the queries k_final could not prove, kernels of their own so that profiles list them apart)
     expect = sorted((t, str(tnq), str(dbg), sample) for t in ("DF16_", "f")
                     for tnq, dbg, sample in ((64, 12, "0"), (64, 13, "0"), (64, 12, "1"), (64, 13, "1"), (256, 0, "0"),
-                                             (256, 12, "0"), (256, 12, "1")))
+                                             (256, 12, "0"), (256, 12, "1"), (64, 32, "0"), (64, 33, "0"), (256, 20, "0"),
+                                             (256, 32, "0")))
     assert variants == expect
     gemm = sorted(set(re.findall(r"k_gemm_f16_(dma|big)ILi(\d+)E", out)))
     assert gemm == [("big", "0"), ("dma", "0")]
