@@ -1452,13 +1452,14 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void k_final2(
                                         ? isc_make_key((float)(dot / denom), (int)isc_perm_orig(pm, row))
                                         : 0ull;
                       });
-        __syncthreads();  // the keys were written by other waves of this workgroup (same CU, write-through L1)
+        // The keys were written by other waves of THIS workgroup: one CU, one vector L1, through which both the stores and
+        // the loads below go -- workgroup scope, which is what __syncthreads() orders (an L1-bypassing load could overtake
+        // a store still on its way to the L2).  The volatile access keeps the compiler from reusing the Cand it read before.
+        __syncthreads();
         unsigned long long key[SEL_PER + 1];
+        const volatile unsigned long long* vkeys = keys;
 #pragma unroll
-        for (int j = 0; j < SEL_PER; ++j)
-            key[j] = tid + SEL_THREADS * j < cnt
-                         ? __hip_atomic_load(keys + tid + SEL_THREADS * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                         : 0ull;
+        for (int j = 0; j < SEL_PER; ++j) key[j] = tid + SEL_THREADS * j < cnt ? vkeys[tid + SEL_THREADS * j] : 0ull;
         key[SEL_PER] = 0ull;
         n = wg_select_keys(sh, key, k);
     }

@@ -309,7 +309,56 @@ def f_merge():
     report("merge", ok, f"G{gq} q{q} kin{kin} kout{kout}")
 
 
-for name, fn in (("normalize", f_normalize), ("resize", f_resize), ("conv", f_conv), ("gemm", f_gemm),
+def f_head():
+    """isc_pool_linear_l2norm against torch: random image counts (odd ones leave a half-empty workgroup), map sizes, widths."""
+    b = int(rng.integers(1, 12))
+    h, w = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    c = int(rng.choice([4, 64, 100, 512, 2048]))
+    e = int(rng.choice([1, 7, 64, 768, 1000]))
+    if 2 * (c + e) * 4 > 64 * 1024:
+        e = 64
+    g = gen()
+    x = torch.randn(b, h, w, c, generator=g)
+    wt = torch.randn(e, c, generator=g) / c**0.5
+    bias = torch.randn(e, generator=g) if rng.random() < 0.7 else None
+    norm = int(rng.random() < 0.5)
+    xd, wd = x.to(dev), wt.to(dev)
+    bd = bias.to(dev) if bias is not None else None
+    out = torch.empty((b, e), device=dev)
+    _lib.check(lib.isc_pool_linear_l2norm(xd.data_ptr(), b, h, w, c, wd.data_ptr(), _lib.ptr(bd), e, norm, 1e-12, out.data_ptr(),
+                                          _lib.stream_handle(dev)), "isc_pool_linear_l2norm")
+    exp = x.double().mean(dim=(1, 2)) @ wt.double().T + (bias.double() if bias is not None else 0.0)
+    if norm:
+        exp = F.normalize(exp, dim=1)
+    exp = exp.float()
+    err = float((out.cpu() - exp).abs().max() / exp.abs().max().clamp_min(1e-30))
+    report("head", err < 5e-6, f"B{b} {h}x{w} C{c} E{e} bias={bias is not None} norm={norm} rel err {err:.3g}")
+
+
+def f_pca_fit():
+    """PCA.fit on the device (feature sums, centred transpose, Gram on the matrix cores, host eigh) against the float64
+    covariance of the same rows: eigenvalues and the projector onto the kept axes."""
+    from imagescry_amd import PCA
+    n, f = int(rng.integers(2, 3000)), int(rng.choice([1, 3, 4, 17, 64, 130]))
+    g = gen()
+    x = torch.randn(n, f, generator=g) @ torch.randn(f, f, generator=g) + 10.0 * torch.randn(1, f, generator=g)
+    kmax = int(rng.integers(1, f + 1))
+    PCA.GRAM_CHUNK_ROWS = int(rng.choice([32, 512, 32768]))  # several chunks on small inputs too
+    pca = PCA(max_num_components=kmax, min_explained_variance=1.0).fit(x.to(dev))
+    PCA.GRAM_CHUNK_ROWS = 32768
+    xc = x.double() - x.double().mean(dim=0, keepdim=True)
+    ev = torch.linalg.eigvalsh(xc.T @ xc / (n - 1)).flip(0).clamp_min(0)
+    rank = min(n, f)
+    want = (ev[:rank] / ev[:rank].sum()).float()
+    got = pca.explained_variance.cpu()
+    ok = got.shape == want.shape and torch.allclose(got, want, rtol=2e-3, atol=2e-5)
+    comp = pca.component_vectors.cpu().double()
+    ok = ok and torch.allclose(comp.T @ comp, torch.eye(comp.shape[1], dtype=torch.float64), atol=1e-4)
+    ok = ok and torch.allclose(pca.feature_means.cpu(), x.mean(dim=0, keepdim=True), rtol=1e-5, atol=1e-5)
+    report("pca_fit", ok, f"n{n} f{f} kmax{kmax} max ev err {(got - want).abs().max():.3g}")
+
+
+for name, fn in (("head", f_head), ("pca_fit", f_pca_fit), ("normalize", f_normalize), ("resize", f_resize), ("conv", f_conv), ("gemm", f_gemm),
                  ("attention", f_attention), ("layernorm", f_layernorm), ("dwconv", f_dwconv),
                  ("gated conv + linear_centered", f_gated_and_centered), ("pools + l2norm", f_pools_l2norm), ("merge", f_merge)):
     if only is None or any(o in name for o in only):
