@@ -70,7 +70,7 @@ constexpr int SEL_THREADS = 512;
 constexpr int SURV_CAP = 2048;  // candidates the selection's exact ranking step accepts
 constexpr int TAIL_LCAP = 256;                       // k_dots_filter tail: LDS list entries per query (= rows of a tile)
 constexpr int TAIL_COUNT_OFF = 64 * TAIL_LCAP * 8;   // ... byte offsets inside the (by then free) staging LDS
-constexpr int TAIL_LBOUND_OFF = TAIL_COUNT_OFF + 1024;
+constexpr int TAIL_LBOUND_OFF = 140 * 1024;  // past the slot maxima of the sample epilogue ([256][128 + 4] floats = 132 KiB)
 
 struct Cand {
     float s;
@@ -888,13 +888,15 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                     for (int n = 0; n < 4; ++n) acc[m][n][r] = -INFINITY;
                 }
         if (nslots > 0) {
-            float* smax = reinterpret_cast<float*>(lds);                       // [TNQ][nslots] (<= 128 KiB)
+            float* smax = reinterpret_cast<float*>(lds);                       // [TNQ][nslots + 4] (<= 132 KiB)
+            const int sstride = nslots + 4;  // rows 16 bytes longer than a power of two: the 16 query rows a wave writes at
+                                             // once would otherwise all start in the same LDS bank
             float* lbound = reinterpret_cast<float*>(lds + TAIL_LBOUND_OFF);  // [TNQ], past the tail's lists
             const int gsz = TM / nslots;                    // scores per slot: 8, 4 or 2
             const int per_lane = MB * 4 / gsz;              // slots per lane and query column
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                float* dst = smax + (size_t)(wn * 64 + n * 16 + frow) * nslots + (wm * 4 + fg) * per_lane;
+                float* dst = smax + (size_t)(wn * 64 + n * 16 + frow) * sstride + (wm * 4 + fg) * per_lane;
                 float cur = -INFINITY;
 #pragma unroll
                 for (int e = 0; e < MB * 4; ++e) {
@@ -910,8 +912,8 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             // is read 16 bytes at a time, two reads in flight: a scalar loop pays one LDS latency per element.
             for (int id = tid; id < TNQ * nslots; id += NTHREADS) {
                 const int qc = id / nslots, sl = id - qc * nslots;
-                const float4* row4 = reinterpret_cast<const float4*>(smax + (size_t)qc * nslots);
-                const float v = smax[(size_t)qc * nslots + sl];
+                const float4* row4 = reinterpret_cast<const float4*>(smax + (size_t)qc * sstride);
+                const float v = smax[(size_t)qc * sstride + sl];
                 int rank = 0;
 #pragma unroll 2
                 for (int j4 = 0; j4 < nslots / 4; ++j4) {
@@ -969,14 +971,23 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                 for (int n = 0; n < 4; ++n) {
                     const int qc = (PASSES == 1 ? wn * 64 : 0) + n * 16 + frow;
                     if constexpr (SAMPLE) {
+                        // count this lane's survivors of the query first, then ONE LDS atomic for all of them: one atomic
+                        // per survivor was a dependent LDS round trip in nearly every one of the 128 element slots of a
+                        // wave (some lane always holds a survivor), 30 us of the 73 us sample launch at Q = 1024
+                        int mine = 0;
+#pragma unroll
+                        for (int m = 0; m < MB; ++m)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) mine += acc[m][n][r] > thr[n] ? 1 : 0;  // rows past the end are -inf
+                        int pos = mine > 0 ? atomicAdd(&lcount[qc], mine) : 0;
 #pragma unroll
                         for (int m = 0; m < MB; ++m)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const float sc = acc[m][n][r];
-                                if (sc > thr[n]) {  // rows past the end are -inf and never pass
-                                    const int pos = atomicAdd(&lcount[qc], 1);
+                                if (sc > thr[n]) {
                                     if (pos < LCAP) lists[qc * LCAP + pos] = Cand{sc, (int32_t)(trow0 + m * 16 + r)};
+                                    ++pos;
                                 }
                             }
                     } else {
