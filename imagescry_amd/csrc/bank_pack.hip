@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k_bank_pack(const TIN* __restrict__ x, in
     const int lane = threadIdx.x & 63;
     const TIN* p = x + r * ldx;
     float denom = 1.f;
-    if (normalize) {
+    if (normalize) {  // (element order of the sum: lane, lane + 64, ... -- kept as it was: the stored values depend on it)
         float acc = 0.f;
         for (int i = lane; i < d; i += 64) {
             const float v = (float)p[i];
@@ -28,17 +28,32 @@ __global__ __launch_bounds__(256) void k_bank_pack(const TIN* __restrict__ x, in
         denom = fmaxf(sqrtf(isc_wave_sum(acc)), eps);
     }
     constexpr int PER_CHUNK = 16 / (int)sizeof(TOUT);
+    constexpr int IN_VECS = PER_CHUNK * (int)sizeof(TIN) / 16;  // 16-byte input loads per output chunk: 1, 2, or 0 (f16 -> f32)
     const int chunks = ks * 8;
     const int64_t row = isc_perm_pos(pm, first_row + r);
+    // rows whose chunks can be fetched with 16-byte loads (a wave instruction then reads 1 KiB of the row instead of 64
+    // scattered 2- or 4-byte elements)
+    const bool vec_ok = IN_VECS > 0 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
     float stored_sq = 0.f;
     for (int c = lane; c < chunks; c += 64) {
         TOUT v[PER_CHUNK];
+        float f[PER_CHUNK];
+        const int e0 = c * PER_CHUNK;
+        if (vec_ok && e0 + PER_CHUNK <= d) {
+            TIN raw[PER_CHUNK];
+#pragma unroll
+            for (int u = 0; u < (IN_VECS > 0 ? IN_VECS : 1); ++u)
+                reinterpret_cast<uint4*>(raw)[u] = reinterpret_cast<const uint4*>(p + e0)[u];
+#pragma unroll
+            for (int j = 0; j < PER_CHUNK; ++j) f[j] = (float)raw[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER_CHUNK; ++j) f[j] = e0 + j < d ? (float)p[e0 + j] : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < PER_CHUNK; ++j) {
-            const int e = c * PER_CHUNK + j;
-            float f = e < d ? (float)p[e] : 0.f;
-            if (normalize && e < d) f = __fdiv_rn(f, denom);
-            v[j] = (TOUT)f;
+            if (normalize && e0 + j < d) f[j] = __fdiv_rn(f[j], denom);
+            v[j] = (TOUT)f[j];
             const float s = (float)v[j];
             stored_sq = fmaf(s, s, stored_sq);
         }
@@ -50,8 +65,13 @@ __global__ __launch_bounds__(256) void k_bank_pack(const TIN* __restrict__ x, in
         // float32 summation of d squares: relative error <= d * 2^-24 -- cover it (and the sqrt) with a factor
         const float nb = sqrtf(stored_sq) * (1.f + 1e-3f);
         // non-negative floats order as uints; a row holding NaN makes the bound +inf: the search then trusts no filter
-        // result on this bank and answers through its exhaustive pass
-        if (lane == 0) atomicMax(norm_bound, nb == nb ? __float_as_uint(nb) : 0x7f800000u);
+        // result on this bank and answers through its exhaustive pass.  The atomic goes out only when this row RAISES the
+        // bound as this wave sees it (a plain read first): one atomic per row on the one word was the whole kernel --
+        // 88 atomics per microsecond on one address, 11.4 ms per 2^20 rows whatever their size.
+        if (lane == 0) {
+            const unsigned mine = nb == nb ? __float_as_uint(nb) : 0x7f800000u;
+            if (mine > __hip_atomic_load(norm_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(norm_bound, mine);
+        }
     }
 }
 
