@@ -43,6 +43,7 @@
 //   TNQ = 64   256 bank rows x  64 queries, waves 8 x 1 (32 x 64 each), a 4-deep ring for both operands: the
 //              HBM-bound shape for small query batches -- three 32 KiB bank blocks are in flight per CU while the
 //              matrix cores idle most of the time.
+#include <math.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -162,7 +163,12 @@ Plan make_plan(int64_t n, int q, int k) {
     add(0, seen, 1);
     while (seen < n) {
         const int64_t nseg = (int64_t)p.segs_per_chunk * wgs;
-        int64_t budget = QCAP / 2;
+        // The level's survivors per query are ~ (ratio - 1) x G with G ~ Gamma(kp): the threshold is the kp-th best of what
+        // was seen, so the tail mass above it fluctuates by 1 / sqrt(kp).  Half the list for the MEAN (round 2) overflowed
+        // the 8192-entry list of about one query in 500 at kp = 16 (P(G > 32) = 2e-3): with 512 queries per call nearly
+        // every search of a bank that uses the full ratio paid a second pass for it.  The list now holds the mean plus
+        // eight standard deviations (kp = 16: ratio 171, P < 1e-8).
+        int64_t budget = (int64_t)((double)QCAP * p.kp / (p.kp + 8.0 * sqrt((double)p.kp)));
         if (nseg * CAP / 8 < budget) budget = nseg * CAP / 8;
         int64_t ratio = 1 + budget / p.kp;
         // 256-query shape with ONE query tile (128 < Q <= 256): the level after the sample would be the whole bank on
