@@ -649,3 +649,28 @@ def test_zero_and_nonfinite_queries_need_no_second_search(device: torch.device) 
     eb2 = _bank(bank, device, index_base=1000, presharded=True)
     s2, i2 = eb2.search(queries.to(device), 8)
     assert i2[1].cpu().tolist() == list(range(1000, 1008))
+
+
+def test_level_lists_do_not_overflow_on_iid_banks(device: torch.device) -> None:
+    """Regression: a level that is R times the rows seen before lets ~ (R - 1) x Gamma(kp) rows per query through, and with
+    the list sized for twice the MEAN about one query in 500 overflowed it at kp = 16 -- with 512 queries per call nearly
+    every search of a bank large enough to use the full ratio (> 8.4 M rows at 257 < Q <= 512) paid a second pass.  The
+    ratio now leaves eight standard deviations: no candidate buffer may overflow on an iid bank, whatever the queries."""
+    n, d, q = 6_500_000, 64, 512
+    g = torch.Generator(device=device).manual_seed(5)
+    bank = torch.nn.functional.normalize(torch.randn(n, d, generator=g, device=device), dim=1).half()
+    from imagescry_amd import EmbeddingBank
+
+    eb = EmbeddingBank(bank, dtype=torch.float16, normalize=False)
+    del bank
+    overflowed = exhaustive = 0
+    for seed in range(6):
+        queries = torch.randn(q, d, generator=torch.Generator().manual_seed(300 + seed)).half().to(device)
+        scores, indices = eb.search(queries, 10)
+        st = eb.last_status.cpu().tolist()
+        overflowed += st[0]
+        exhaustive += st[3]
+    assert overflowed == 0 and exhaustive == 0, (overflowed, exhaustive)
+    # the last answer against the exhaustive float64 kernel (a handful of queries: it sweeps the bank per four)
+    es, ei = eb.search_exhaustive(queries[:8], 10)
+    assert torch.equal(indices[:8], ei) and torch.equal(scores[:8], es)
