@@ -368,7 +368,7 @@ constexpr int A_TILE_BYTES = TM * 128;  // 32 KiB: one K step of one bank tile
 //
 // DBG: 0 = production, 12 = production with every wave issuing its own share of the LDS-DMA (used when several query-tile
 // workgroups stream the same chunk).  The other values exist only in -DISC_ABLATION builds (wrong results by design):
-// 2 = no staging after the prologue, 3 = staging but no MFMAs, 7 = like 2 without LDS fragment reads, 11 = no
+// 2 = no staging after the prologue, 3 = staging but no MFMAs, 41 / 43 = the query operand ablations, 7 = like 2 without LDS fragment reads, 11 = no
 // half-row-block stagger of the wm = 1 waves, 15 = DMA issued but never waited for, 17 = DMA and MFMAs but no LDS
 // fragment reads.
 template <typename T, int TNQ, int DBG, bool SAMPLE>
@@ -403,7 +403,11 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 #ifndef ISC_ASYM_SPLIT_MBLO
 #define ISC_ASYM_SPLIT_MBLO 8
 #endif
-    constexpr bool NOSPLIT_FORM = MODE == 12 || MODE == 22;
+    // Ablations of the query operand (what do its LDS bytes cost?  DESIGN 8, scripts/ab_noq.sh): 41 = neither staged nor
+    // read (garbage fragments), 43 = staged (LDS-DMA writes) but never read.
+    constexpr bool NOBREAD = (MODE == 41 || MODE == 43) && TNQ == 256;
+    constexpr bool NOBDMA = MODE == 41 && TNQ == 256;
+    constexpr bool NOSPLIT_FORM = MODE == 12 || MODE == 22 || MODE == 41 || MODE == 43;
     constexpr int ASYM_LO = NOSPLIT_FORM ? ISC_ASYM_MBLO : MODE == 0 ? ISC_ASYM_SPLIT_MBLO : 8;
     constexpr bool ASYM = TNQ == 256 && !SAMPLE && ASYM_LO != 8;
     constexpr int MBLO = ASYM ? ASYM_LO : MB;        // row blocks of a wm = 0 wave
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     // wave + 8 i), so the wm = 1 wave of every SIMD never waits on a vector-memory issue slot and keeps the matrix
     // pipe fed while its partner is held up by the back-pressure of the L2 -> LDS path (+1 % at Q = 1024, +3.5 % at
     // Q = 256; MODE 12 = every wave issues its own share, the A/B reference)
-    constexpr bool SPLIT = TNQ == 256 && MODE != 12 && MODE != 22;  // 22 = 12 + in-kernel stamps (ablation builds)
+    constexpr bool SPLIT = TNQ == 256 && !NOSPLIT_FORM;  // 22 = 12 + in-kernel stamps (ablation builds)
     // NT: the launch has ONE query tile, so every bank byte is read by exactly one workgroup, once: stream it with the
     // non-temporal policy (MODE 0 = the single-query-tile form of the 256-query shape, MODE 13 = of the 64-query shape)
     constexpr bool NT = (TNQ == 256 && MODE == 0) || MODE == 13;
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     auto issue_iter = [&](int it) {
         if ((MODE == 2 || MODE == 7) && it >= 0) return;
         const int sb = it + DB, sa = it + DA;
-        if (sb >= 0 && sb < total_steps) issue_b(sb);
+        if (!NOBDMA && sb >= 0 && sb < total_steps) issue_b(sb);
         if (sa >= 0 && sa < total_steps) issue_a(sa);
     };
     // after iteration `next - 1` has issued: retire everything step `next` needs, leave the younger DMA in flight
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     // The condition must be provably wave-uniform: s_setprio is a scalar instruction that ignores EXEC.
     // Not with SPLIT (MODE 0: only the older half issues the LDS-DMA there, and prioritising the other half on top of
     // that cost 4 %).
-    if constexpr (TNQ == 256 && (MODE == 12 || MODE == 22)) {
+    if constexpr (TNQ == 256 && NOSPLIT_FORM) {
 #ifdef ISC_ABLATION
         if (!((nslots >> 18) & 1))
 #endif
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             constexpr int MBW = STAGGER ? MBHI : MBLO;  // row blocks of this wave (the wm = 1 waves run the STAGGER copy)
             static_assert(MBW >= 3 && MBW <= MBMAX, "row blocks per wave");
             const int sb = step + DB, sa = step + DA;
-            const bool do_b = MODE != 2 && sb < total_steps;
+            const bool do_b = MODE != 2 && !NOBDMA && sb < total_steps;
             const bool do_a = MODE != 2 && sa < total_steps;
             const unsigned char* bsrc = b_stream + (int64_t)(sb % ksteps) * B_TILE_BYTES;
             unsigned char* bdst = lds_b + (sb % B_ST) * B_TILE_BYTES + wave_dst;
@@ -604,6 +608,13 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             const unsigned a_addr0 = a_addr + foff[0], a_addr1 = a_addr + foff[1];
             const unsigned b_addr0 = b_addr + foff[0], b_addr1 = b_addr + foff[1];
             u32x4 b0[4], b1[4], ar[3][2];
+            constexpr int NBR = NOBREAD ? 0 : 4;  // query fragment reads per half K step
+            if constexpr (NOBREAD) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b0[i] = b1[i] = u32x4{(unsigned)step, 1u, 2u, (unsigned)lane};
+                ISC_DS_READ(ar[0][0], a_addr0, 0);
+                ISC_DS_READ(ar[0][1], a_addr1, 0);
+            } else {
             ISC_DS_READ(b0[0], b_addr0, 0);  // R0: what the first four MFMAs need
             ISC_DS_READ(b0[1], b_addr0, 2048);
             ISC_DS_READ(b0[2], b_addr0, 4096);
@@ -614,6 +625,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             ISC_DS_READ(b1[2], b_addr1, 4096);
             ISC_DS_READ(b1[3], b_addr1, 6144);
             ISC_DS_READ(ar[0][1], a_addr1, 0);
+            }
             ISC_DS_READ(ar[1][0], a_addr0, 2048);  // R2
             ISC_DS_READ(ar[1][1], a_addr1, 2048);
             // LDS-DMA piece j of this iteration (j < 4: the query step, then the bank step).  SPLIT: the wm = 0 loop issues two
@@ -660,7 +672,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             // blocks, so one partner is always issuing MFMAs.
             if constexpr (STAGGER) {
                 // ---- type B: [first half of block m] [reads m + 2, DMA, wait for block m + 1] [second half of block m]
-                asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(ar[0][0]));
+                asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(ar[0][0]) : "i"(NBR + 3));
                 __builtin_amdgcn_sched_barrier(0);
                 ISC_MFMA_HALF(ar[0][0], b0, 0)
                 ISC_DS_READ(ar[2][0], a_addr0, 4096);  // R3
@@ -694,7 +706,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                 // ---- type A.  row block 0: its two halves arrive separately
                 ISC_DS_READ(ar[2][0], a_addr0, 4096);  // R3
                 ISC_DS_READ(ar[2][1], a_addr1, 4096);
-                asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(ar[0][0]));
+                asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(ar[0][0]) : "i"(NBR + 5));
                 __builtin_amdgcn_sched_barrier(0);
                 dma_at(std::integral_constant<int, 0>{});
                 ISC_MFMA_HALF(ar[0][0], b0, 0)
@@ -1598,6 +1610,8 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const Filt
         case 15: ISC_LAUNCH_FILTER(15, false); break;
         case 17: ISC_LAUNCH_FILTER(17, false); break;
         case 22: ISC_LAUNCH_FILTER(22, false); break;
+        case 41: ISC_LAUNCH_FILTER(41, false); break;
+        case 43: ISC_LAUNCH_FILTER(43, false); break;
 #endif
         case 12: ISC_LAUNCH_FILTER(12, false); break;
         default:
