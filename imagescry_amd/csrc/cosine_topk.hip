@@ -304,6 +304,14 @@ struct Mma<_Float16> {
         half(a0, b[0], acc);
         half(a1, b[1], acc);
     }
+    // query blocks N0 .. N1 - 1 of `half` (the same instructions in the same order per accumulator)
+    template <int N0, int N1>
+    static __device__ __forceinline__ void part(const u32x4& a, const u32x4 (&b)[4], f32x4 (&acc)[4]) {
+#pragma unroll
+        for (int n = N0; n < N1; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a),
+                                                            __builtin_bit_cast(half8, b[n]), acc[n], 0, 0, 0);
+    }
 };
 
 template <>
@@ -323,6 +331,15 @@ struct Mma<float> {
                                                f32x4 (&acc)[4]) {
         half(a0, b[0], acc);
         half(a1, b[1], acc);
+    }
+    template <int N0, int N1>
+    static __device__ __forceinline__ void part(const u32x4& a, const u32x4 (&b)[4], f32x4 (&acc)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = N0; n < N1; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[n][j]), acc[n],
+                                                              0, 0, 0);
     }
 };
 
@@ -407,7 +424,13 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     // read (garbage fragments), 43 = staged (LDS-DMA writes) but never read.
     constexpr bool NOBREAD = (MODE == 41 || MODE == 43) && TNQ == 256;
     constexpr bool NOBDMA = MODE == 41 && TNQ == 256;
-    constexpr bool NOSPLIT_FORM = MODE == 12 || MODE == 22 || MODE == 41 || MODE == 43;
+    // HM: the K step in half-major order -- [all row blocks x first 32 k] [all row blocks x second 32 k] -- so that only
+    // the first half's query fragments stand between the barrier and the first MFMA of a step (the second half's are
+    // fetched under the first units), and the bank fragments run three units ahead through four registers.
+    // It is the form of every launch with several query tiles (MODE 12); MODE 48 (ablation builds) = the row-block-major
+    // form it replaced (+1.6 %, scripts/ab_hm.sh), which the stamped build (22) and the operand ablations (41, 43) still run.
+    constexpr bool HM = MODE == 12 && TNQ == 256 && !SAMPLE;
+    constexpr bool NOSPLIT_FORM = MODE == 12 || MODE == 22 || MODE == 41 || MODE == 43 || MODE == 48;
     constexpr int ASYM_LO = NOSPLIT_FORM ? ISC_ASYM_MBLO : MODE == 0 ? ISC_ASYM_SPLIT_MBLO : 8;
     constexpr bool ASYM = TNQ == 256 && !SAMPLE && ASYM_LO != 8;
     constexpr int MBLO = ASYM ? ASYM_LO : MB;        // row blocks of a wm = 0 wave
@@ -447,7 +470,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         thr[n] = tau[q0 + wn * 64 + n * 16 + frow];
-        if ((MODE != 0 && MODE < 11) || MODE >= 15) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
+        if ((MODE != 0 && MODE < 11) || (MODE >= 15 && MODE != 48)) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ablations: nothing survives (kept opaque to the optimiser)
 #ifdef ISC_ABLATION
         if (!SAMPLE && g_abl_thr_inf) thr[n] = fabsf(thr[n]) + 3.0e38f;  // ISC_THR_INF: the price of scanning + the tail
 #endif
@@ -588,7 +611,117 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     int kt = 0, tile = 0;
     if constexpr (MODE == 22) st_prev = stamp();
     for (int step = 0; step < total_steps; ++step) {
-        if constexpr (TNQ == 256 && MODE != 7 && MODE != 17) {
+        if constexpr (HM) {
+            // ---- 256-query shape, half-major.  A K step is 2 MBW units: unit u = (row block u % MBW, half u / MBW), four
+            // MFMAs (fp16) each.  LDS read stream of a wave and step (the LDS returns in order; every counted wait below is
+            // derived from it): [b0 x 4, a(0), a(1), a(2)] then per unit v: [b1[v] if v < 4] [a(v + 3) if it exists].  Bank
+            // fragments run three units ahead through a ring of four registers; the second half's query fragments are
+            // fetched under the first four units.  The eight LDS-DMA pieces (query step, then bank step) are spread over
+            // the units after the first.
+            constexpr int MBW = STAGGER ? MBHI : MBLO;
+            constexpr int NU = 2 * MBW;
+            static_assert(MBW >= 6, "b1 is fetched under units 0 - 3 and first used by unit MBW");
+            const int sb = step + DB, sa = step + DA;
+            const bool do_b = sb < total_steps;
+            const bool do_a = sa < total_steps;
+            const unsigned char* bsrc = b_stream + (int64_t)(sb % ksteps) * B_TILE_BYTES;
+            unsigned char* bdst = lds_b + (sb % B_ST) * B_TILE_BYTES + wave_dst;
+            const unsigned char* asrc = a_stream + (int64_t)sa * A_TILE_BYTES;
+            unsigned char* adst = lds_a + (sa % A_ST) * A_TILE_BYTES + wave_dst;
+            const unsigned a_addr = lds_a_addr + (unsigned)((step % A_ST) * A_TILE_BYTES + a_wave_off);
+            const unsigned b_addr = lds_b_addr + (unsigned)((step % B_ST) * B_TILE_BYTES + b_wave_off);
+            const unsigned a_addr0 = a_addr + foff[0], a_addr1 = a_addr + foff[1];
+            const unsigned b_addr0 = b_addr + foff[0], b_addr1 = b_addr + foff[1];
+            u32x4 b0[4], b1[4], ar[4];
+            ISC_DS_READ(b0[0], b_addr0, 0);
+            ISC_DS_READ(b0[1], b_addr0, 2048);
+            ISC_DS_READ(b0[2], b_addr0, 4096);
+            ISC_DS_READ(b0[3], b_addr0, 6144);
+            auto read_unit = [&](auto uc) {
+                constexpr int u = decltype(uc)::value, m = u % MBW, kk = u / MBW;
+                auto& frag = ar;  // (named outside the asm so that the lambda captures them)
+                const unsigned addr = kk == 0 ? a_addr0 : a_addr1;
+                ISC_DS_READ(frag[u & 3], addr, m * 2048);
+            };
+            read_unit(std::integral_constant<int, 0>{});
+            read_unit(std::integral_constant<int, 1>{});
+            read_unit(std::integral_constant<int, 2>{});
+            // reads the overhead of unit v issues, and how many reads are newer than a(w) once the overhead of unit u is out
+#ifndef ISC_HM_DMA0
+#define ISC_HM_DMA0 1
+#endif
+#ifndef ISC_HM_B1U
+#define ISC_HM_B1U 2
+#endif
+            constexpr int B1U = ISC_HM_B1U < MBW - 6 ? ISC_HM_B1U : MBW - 6;  // b1[3] must go out before a(MBW)
+            constexpr int DMA0 = ISC_HM_DMA0;
+            auto reads_of = [](int v) constexpr { return (v >= B1U && v < B1U + 4 ? 1 : 0) + (v + 3 < NU ? 1 : 0); };
+            auto newer_than = [reads_of](int w, int u) constexpr {
+                int c = w < 3 ? 2 - w : 0;
+                for (int v = w < 3 ? 0 : w - 2; v <= u; ++v) c += reads_of(v);
+                return c;
+            };
+            // LDS-DMA piece j (j < 4: query step, then the bank step) goes out in the overhead of unit 1 + j (NU - 2) / 8
+            auto overhead = [&](auto uc, auto wc) {
+                constexpr int u = decltype(uc)::value, w = decltype(wc)::value;  // w: the unit whose fragment must be there
+                if constexpr (u >= B1U && u < B1U + 4) {
+                    auto& q1 = b1;
+                    const unsigned addr = b_addr1;
+                    ISC_DS_READ(q1[u - B1U], addr, (u - B1U) * 2048);
+                }
+                if constexpr (u + 3 < NU) read_unit(std::integral_constant<int, u + 3>{});
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (DMA0 + j * (NU - 1 - DMA0) / 8 != u) continue;
+                    if (j < 4) {
+                        if (do_b) glds16(bsrc + 8192 * j, bdst + 8192 * j);
+                    } else {
+                        if (do_a) glds16_bank<NT>(asrc + 8192 * (j - 4), adst + 8192 * (j - 4));
+                    }
+                }
+                if constexpr (w < NU) {
+                    auto& frag = ar;
+                    auto& q0 = b0;
+                    auto& q1 = b1;
+                    if constexpr (w == 0)
+                        asm volatile("s_waitcnt lgkmcnt(%5)"
+                                     : "+v"(frag[0]), "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3])
+                                     : "i"(newer_than(0, u)));
+                    else if constexpr (w == MBW)
+                        asm volatile("s_waitcnt lgkmcnt(%5)"
+                                     : "+v"(frag[w & 3]), "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3])
+                                     : "i"(newer_than(w, u)));
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag[w & 3]) : "i"(newer_than(w, u)));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if constexpr (STAGGER) {
+                // type B: [MFMAs 0-1 of unit u] [overhead, wait for unit u + 1] [MFMAs 2-3 of unit u]
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ar[0]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]));
+                __builtin_amdgcn_sched_barrier(0);
+                auto units = [&](auto self, auto uc) {
+                    constexpr int u = decltype(uc)::value, m = u % MBW, kk = u / MBW;
+                    if constexpr (kk == 0) Mma<T>::template part<0, 2>(ar[u & 3], b0, acc[m]);
+                    else Mma<T>::template part<0, 2>(ar[u & 3], b1, acc[m]);
+                    overhead(uc, std::integral_constant<int, u + 1>{});
+                    if constexpr (kk == 0) Mma<T>::template part<2, 4>(ar[u & 3], b0, acc[m]);
+                    else Mma<T>::template part<2, 4>(ar[u & 3], b1, acc[m]);
+                    if constexpr (u + 1 < NU) self(self, std::integral_constant<int, u + 1>{});
+                };
+                units(units, std::integral_constant<int, 0>{});
+            } else {
+                // type A: [overhead, wait for unit u] [MFMAs 0-3 of unit u]
+                auto units = [&](auto self, auto uc) {
+                    constexpr int u = decltype(uc)::value, m = u % MBW, kk = u / MBW;
+                    overhead(uc, uc);
+                    if constexpr (kk == 0) Mma<T>::template part<0, 4>(ar[u & 3], b0, acc[m]);
+                    else Mma<T>::template part<0, 4>(ar[u & 3], b1, acc[m]);
+                    if constexpr (u + 1 < NU) self(self, std::integral_constant<int, u + 1>{});
+                };
+                units(units, std::integral_constant<int, 0>{});
+            }
+        } else if constexpr (TNQ == 256 && MODE != 7 && MODE != 17) {
             // ---- 256-query shape.  One K step = MBW row blocks of 8 MFMAs (fp16) for this wave.  Fragment reads run two
             // row blocks ahead of the matrix cores (LDS returns in order: lgkmcnt(4) = "all but the newest two blocks"), and
             // the eight LDS-DMA instructions of this iteration are spread over the row blocks, so their issue cost hides
@@ -1612,6 +1745,7 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const Filt
         case 22: ISC_LAUNCH_FILTER(22, false); break;
         case 41: ISC_LAUNCH_FILTER(41, false); break;
         case 43: ISC_LAUNCH_FILTER(43, false); break;
+        case 48: ISC_LAUNCH_FILTER(48, false); break;
 #endif
         case 12: ISC_LAUNCH_FILTER(12, false); break;
         default:
