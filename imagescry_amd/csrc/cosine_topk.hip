@@ -620,7 +620,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             // the units after the first.
             constexpr int MBW = STAGGER ? MBHI : MBLO;
             constexpr int NU = 2 * MBW;
-            static_assert(MBW >= 6, "b1 is fetched under units 0 - 3 and first used by unit MBW");
+            static_assert(MBW >= 4, "the second half's query fragments are fetched under four units of the first");
             const int sb = step + DB, sa = step + DA;
             const bool do_b = sb < total_steps;
             const bool do_a = sa < total_steps;
@@ -632,7 +632,11 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             const unsigned b_addr = lds_b_addr + (unsigned)((step % B_ST) * B_TILE_BYTES + b_wave_off);
             const unsigned a_addr0 = a_addr + foff[0], a_addr1 = a_addr + foff[1];
             const unsigned b_addr0 = b_addr + foff[0], b_addr1 = b_addr + foff[1];
-            u32x4 b0[4], b1[4], ar[4];
+#ifndef ISC_HM_RING
+#define ISC_HM_RING 4
+#endif
+            constexpr int RING = ISC_HM_RING;  // bank-fragment registers: reads run RING - 1 units ahead
+            u32x4 b0[4], b1[4], ar[RING];
             ISC_DS_READ(b0[0], b_addr0, 0);
             ISC_DS_READ(b0[1], b_addr0, 2048);
             ISC_DS_READ(b0[2], b_addr0, 4096);
@@ -641,11 +645,14 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                 constexpr int u = decltype(uc)::value, m = u % MBW, kk = u / MBW;
                 auto& frag = ar;  // (named outside the asm so that the lambda captures them)
                 const unsigned addr = kk == 0 ? a_addr0 : a_addr1;
-                ISC_DS_READ(frag[u & 3], addr, m * 2048);
+                ISC_DS_READ(frag[u % RING], addr, m * 2048);
             };
             read_unit(std::integral_constant<int, 0>{});
             read_unit(std::integral_constant<int, 1>{});
             read_unit(std::integral_constant<int, 2>{});
+            if constexpr (RING > 4) read_unit(std::integral_constant<int, 3>{});
+            if constexpr (RING > 5) read_unit(std::integral_constant<int, 4>{});
+            static_assert(RING >= 4 && RING <= 6, "prologue reads");
             // reads the overhead of unit v issues, and how many reads are newer than a(w) once the overhead of unit u is out
 #ifndef ISC_HM_DMA0
 #define ISC_HM_DMA0 1
@@ -653,13 +660,27 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
 #ifndef ISC_HM_B1U
 #define ISC_HM_B1U 2
 #endif
-            constexpr int B1U = ISC_HM_B1U < MBW - 6 ? ISC_HM_B1U : MBW - 6;  // b1[3] must go out before a(MBW)
+            constexpr int B1U = ISC_HM_B1U < MBW - 4 ? ISC_HM_B1U : MBW - 4;  // b1[3] is out before unit MBW's fragments are waited for
             constexpr int DMA0 = ISC_HM_DMA0;
-            auto reads_of = [](int v) constexpr { return (v >= B1U && v < B1U + 4 ? 1 : 0) + (v + 3 < NU ? 1 : 0); };
-            auto newer_than = [reads_of](int w, int u) constexpr {
-                int c = w < 3 ? 2 - w : 0;
-                for (int v = w < 3 ? 0 : w - 2; v <= u; ++v) c += reads_of(v);
+            // the read stream: [b0 x 4][a(0 .. RING-2)] then per overhead v: [b1[v - B1U] if B1U <= v < B1U + 4][a(v + RING - 1)]
+            auto reads_of = [](int v) constexpr { return (v >= B1U && v < B1U + 4 ? 1 : 0) + (v + RING - 1 < NU ? 1 : 0); };
+            auto issued_through = [reads_of](int u) constexpr {
+                int c = 4 + RING - 1;
+                for (int v = 0; v <= u; ++v) c += reads_of(v);
                 return c;
+            };
+            auto pos_a = [issued_through](int w) constexpr {  // position of a(w) in the stream
+                if (w < RING - 1) return 4 + w;
+                return issued_through(w - (RING - 1)) - 1;  // the last read of that overhead
+            };
+            auto pos_b1_last = [issued_through]() constexpr {  // b1[3]: first read of overhead B1U + 3
+                return issued_through(B1U + 2);
+            };
+            // reads that may still be in flight when unit w starts, once overhead u is out
+            auto newer_than = [=](int w, int u) constexpr {
+                int need = pos_a(w);
+                if (w >= MBW && pos_b1_last() > need) need = pos_b1_last();
+                return issued_through(u) - 1 - need;
             };
             // LDS-DMA piece j (j < 4: query step, then the bank step) goes out in the overhead of unit 1 + j (NU - 2) / 8
             auto overhead = [&](auto uc, auto wc) {
@@ -669,7 +690,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                     const unsigned addr = b_addr1;
                     ISC_DS_READ(q1[u - B1U], addr, (u - B1U) * 2048);
                 }
-                if constexpr (u + 3 < NU) read_unit(std::integral_constant<int, u + 3>{});
+                if constexpr (u + RING - 1 < NU) read_unit(std::integral_constant<int, u + RING - 1>{});
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (DMA0 + j * (NU - 1 - DMA0) / 8 != u) continue;
@@ -689,24 +710,24 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                                      : "i"(newer_than(0, u)));
                     else if constexpr (w == MBW)
                         asm volatile("s_waitcnt lgkmcnt(%5)"
-                                     : "+v"(frag[w & 3]), "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3])
+                                     : "+v"(frag[w % RING]), "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3])
                                      : "i"(newer_than(w, u)));
                     else
-                        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag[w & 3]) : "i"(newer_than(w, u)));
+                        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag[w % RING]) : "i"(newer_than(w, u)));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
             if constexpr (STAGGER) {
                 // type B: [MFMAs 0-1 of unit u] [overhead, wait for unit u + 1] [MFMAs 2-3 of unit u]
-                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ar[0]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]));
+                asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(ar[0]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]) : "i"(RING - 2));
                 __builtin_amdgcn_sched_barrier(0);
                 auto units = [&](auto self, auto uc) {
                     constexpr int u = decltype(uc)::value, m = u % MBW, kk = u / MBW;
-                    if constexpr (kk == 0) Mma<T>::template part<0, 2>(ar[u & 3], b0, acc[m]);
-                    else Mma<T>::template part<0, 2>(ar[u & 3], b1, acc[m]);
+                    if constexpr (kk == 0) Mma<T>::template part<0, 2>(ar[u % RING], b0, acc[m]);
+                    else Mma<T>::template part<0, 2>(ar[u % RING], b1, acc[m]);
                     overhead(uc, std::integral_constant<int, u + 1>{});
-                    if constexpr (kk == 0) Mma<T>::template part<2, 4>(ar[u & 3], b0, acc[m]);
-                    else Mma<T>::template part<2, 4>(ar[u & 3], b1, acc[m]);
+                    if constexpr (kk == 0) Mma<T>::template part<2, 4>(ar[u % RING], b0, acc[m]);
+                    else Mma<T>::template part<2, 4>(ar[u % RING], b1, acc[m]);
                     if constexpr (u + 1 < NU) self(self, std::integral_constant<int, u + 1>{});
                 };
                 units(units, std::integral_constant<int, 0>{});
@@ -715,8 +736,8 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                 auto units = [&](auto self, auto uc) {
                     constexpr int u = decltype(uc)::value, m = u % MBW, kk = u / MBW;
                     overhead(uc, uc);
-                    if constexpr (kk == 0) Mma<T>::template part<0, 4>(ar[u & 3], b0, acc[m]);
-                    else Mma<T>::template part<0, 4>(ar[u & 3], b1, acc[m]);
+                    if constexpr (kk == 0) Mma<T>::template part<0, 4>(ar[u % RING], b0, acc[m]);
+                    else Mma<T>::template part<0, 4>(ar[u % RING], b1, acc[m]);
                     if constexpr (u + 1 < NU) self(self, std::integral_constant<int, u + 1>{});
                 };
                 units(units, std::integral_constant<int, 0>{});
