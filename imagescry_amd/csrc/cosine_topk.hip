@@ -372,6 +372,24 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 constexpr int A_TILE_BYTES = TM * 128;  // 32 KiB: one K step of one bank tile
 
+// Tuning constants of the 256-query loop.  They are macros so that `python -m imagescry_amd.build --variant=<name> -D...`
+// can build A/B libraries (scripts/ab_asym.sh, scripts/ab_hm.sh); the values below are what the measurements kept.
+#ifndef ISC_ASYM_MBLO
+#define ISC_ASYM_MBLO 6  // row blocks of a wm = 0 wave (of 16 per tile) in launches with several query tiles
+#endif
+#ifndef ISC_ASYM_SPLIT_MBLO
+#define ISC_ASYM_SPLIT_MBLO 8  // ... in the single-query-tile SPLIT form (symmetric)
+#endif
+#ifndef ISC_HM_RING
+#define ISC_HM_RING 4  // half-major loop: bank-fragment registers (reads run RING - 1 units ahead)
+#endif
+#ifndef ISC_HM_DMA0
+#define ISC_HM_DMA0 1  // ... first unit that carries an LDS-DMA piece
+#endif
+#ifndef ISC_HM_B1U
+#define ISC_HM_B1U 2  // ... first unit under which the second half's query fragments are fetched
+#endif
+
 // One workgroup = one query tile x one chunk of consecutive 256-row bank tiles.
 //
 // Pipeline: the K steps of all the chunk's tiles form one stream.  Iteration s issues the LDS-DMA of query step
@@ -414,12 +432,6 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     // (2 890 cycles; without the static priority the roles swap, the picture stays).  So the favoured waves own MBHI of the
     // tile's 16 row blocks and the others MBLO.  Sample launches (one tile per workgroup) and the 64-query shape stay
     // symmetric.
-#ifndef ISC_ASYM_MBLO
-#define ISC_ASYM_MBLO 6
-#endif
-#ifndef ISC_ASYM_SPLIT_MBLO
-#define ISC_ASYM_SPLIT_MBLO 8
-#endif
     // Ablations of the query operand (what do its LDS bytes cost?  DESIGN 8, scripts/ab_noq.sh): 41 = neither staged nor
     // read (garbage fragments), 43 = staged (LDS-DMA writes) but never read.
     constexpr bool NOBREAD = (MODE == 41 || MODE == 43) && TNQ == 256;
@@ -632,9 +644,6 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             const unsigned b_addr = lds_b_addr + (unsigned)((step % B_ST) * B_TILE_BYTES + b_wave_off);
             const unsigned a_addr0 = a_addr + foff[0], a_addr1 = a_addr + foff[1];
             const unsigned b_addr0 = b_addr + foff[0], b_addr1 = b_addr + foff[1];
-#ifndef ISC_HM_RING
-#define ISC_HM_RING 4
-#endif
             constexpr int RING = ISC_HM_RING;  // bank-fragment registers: reads run RING - 1 units ahead
             u32x4 b0[4], b1[4], ar[RING];
             ISC_DS_READ(b0[0], b_addr0, 0);
@@ -654,12 +663,6 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
             if constexpr (RING > 5) read_unit(std::integral_constant<int, 4>{});
             static_assert(RING >= 4 && RING <= 6, "prologue reads");
             // reads the overhead of unit v issues, and how many reads are newer than a(w) once the overhead of unit u is out
-#ifndef ISC_HM_DMA0
-#define ISC_HM_DMA0 1
-#endif
-#ifndef ISC_HM_B1U
-#define ISC_HM_B1U 2
-#endif
             constexpr int B1U = ISC_HM_B1U < MBW - 4 ? ISC_HM_B1U : MBW - 4;  // b1[3] is out before unit MBW's fragments are waited for
             constexpr int DMA0 = ISC_HM_DMA0;
             // the read stream: [b0 x 4][a(0 .. RING-2)] then per overhead v: [b1[v - B1U] if B1U <= v < B1U + 4][a(v + RING - 1)]
