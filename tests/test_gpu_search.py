@@ -63,6 +63,11 @@ def test_exact_ties_go_to_the_lowest_index(dtype: torch.dtype, tag: str, device:
         (266241, 64, 9, 10, torch.float16),  # three levels (4096 | 262144 | rest)
         (70000, 768, 300, 10, torch.float16),  # two query tiles
         (9000, 1536, 17, 10, torch.float32),
+        # several 256-query tiles (the half-major K step of k_dots_filter): an odd number of K steps and a ragged last
+        # tile; an fp32 bank with a zero-padded last K step; four full tiles at the benchmark's D
+        (40000, 192, 513, 10, torch.float16),
+        (30000, 100, 700, 7, torch.float32),
+        (16000, 768, 1024, 10, torch.float16),
     ],
 )
 def test_search_matches_oracle(n: int, d: int, q: int, k: int, dtype: torch.dtype, device: torch.device) -> None:
