@@ -679,3 +679,30 @@ def test_level_lists_do_not_overflow_on_iid_banks(device: torch.device) -> None:
     # the last answer against the exhaustive float64 kernel (a handful of queries: it sweeps the bank per four)
     es, ei = eb.search_exhaustive(queries[:8], 10)
     assert torch.equal(indices[:8], ei) and torch.equal(scores[:8], es)
+
+
+def test_async_searches_in_flight_equal_the_serial_answers(device: torch.device) -> None:
+    """`search_async` alternates between two streams of the bank (each with its own workspace) so that the tail of one
+    search runs beside the head of the next: handles resolved late, in any order, must hold exactly what `search` returns
+    -- with different query counts in flight (different workspace buckets and tile shapes) and the query tensors dropped
+    before their searches have run."""
+    bank, _ = cases.search_case(300_000, 256, 1, torch.float16, seed=77)
+    eb = _bank(bank, device)
+    gen = torch.Generator().manual_seed(78)
+    sizes = [5, 64, 300, 1, 700, 64, 17, 256]
+    expect = []
+    for nq in sizes:
+        qs = torch.randn((nq, 256), generator=gen).half()
+        s, i = eb.search(qs.to(device), 10)
+        expect.append((qs, s.cpu(), i.cpu()))
+    torch.cuda.synchronize()
+    for order in (0, 1):
+        handles = []
+        for qs, _, _ in expect:
+            qd = qs.to(device)
+            handles.append(eb.search_async(qd, 10))
+            del qd  # the lane must keep the queries alive until it has read them
+        seq = range(len(handles)) if order == 0 else reversed(range(len(handles)))
+        for j in seq:
+            s, i = handles[j].result()
+            assert torch.equal(i.cpu(), expect[j][2]) and torch.equal(s.cpu(), expect[j][1])
