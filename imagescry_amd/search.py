@@ -51,6 +51,22 @@ def shard_bounds(n_rows: int, world_size: int, rank: int) -> tuple[int, int]:
     return rank * n_rows // world_size, (rank + 1) * n_rows // world_size
 
 
+# The two streams asynchronous searches alternate between, per DEVICE and shared by every bank on it: the runtime maps
+# streams onto a handful of hardware queues, and streams that share a queue wait for each other -- with a pair per bank, a
+# process holding two banks ran its searches slower asynchronously than serially (0.366 against 0.321 ms at a 1.25 M-row
+# shard).
+_LANE_STREAMS: dict[int, tuple["torch.cuda.Stream", "torch.cuda.Stream"]] = {}
+
+
+def _lane_streams(device: torch.device) -> tuple["torch.cuda.Stream", "torch.cuda.Stream"]:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    pair = _LANE_STREAMS.get(idx)
+    if pair is None:
+        pair = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+        _LANE_STREAMS[idx] = pair
+    return pair
+
+
 class SearchHandle:
     """Result of `EmbeddingBank.search_async`.  The tensors exist at once; their CONTENTS are final when the event
     recorded behind the merge has fired.  `result()` orders the caller's current stream behind that event (no host
@@ -134,7 +150,10 @@ class EmbeddingBank:
         if self.dim == 0:
             raise ValueError("embedding dimension must be positive")
         self._bank = self._store(embeddings, normalize)
-        self._workspaces: dict[tuple[int, int], Tensor] = {}
+        # search workspaces per LANE: -1 = the caller's stream (`search`), 0 / 1 = the two streams `search_async` alternates
+        # between -- two searches in flight must not share a workspace
+        self._workspaces: dict[int, dict[tuple[int, int], Tensor]] = {}
+        self._lane_next = 0
         self._slots = (_ExchangeSlot(), _ExchangeSlot())
         self._slot_next = 0
         self._xstream: "torch.cuda.Stream | None" = None
@@ -241,14 +260,15 @@ class EmbeddingBank:
             raise ValueError(f"queries are on {queries.device} but the bank is on {self.device}")
         return queries.to(self.dtype).contiguous()
 
-    def _workspace(self, n_queries: int, k: int) -> Tensor:
+    def _workspace(self, n_queries: int, k: int, lane: int = -1) -> Tensor:
         """The search workspace.  The C side runs a call as passes of at most `ISC_SEARCH_PASS_QUERIES` queries over
         one workspace and cuts the queries into tiles of 64 (up to 128 queries) or 256, so the size depends on
         (padded queries of a pass, k) only: alternating batch sizes inside one bucket -- a pipeline's short last
-        batch -- reuse one allocation instead of reallocating 150-300 MB per call.  One buffer per bucket is kept."""
+        batch -- reuse one allocation instead of reallocating 150-300 MB per call.  One buffer per bucket and lane is kept."""
         nq = min(n_queries, _lib.ISC_SEARCH_PASS_QUERIES)
         key = (-(-nq // 64) * 64 if nq <= 128 else -(-nq // 256) * 256, k)
-        ws = self._workspaces.get(key)
+        cache = self._workspaces.setdefault(lane, {})
+        ws = cache.get(key)
         if ws is None:
             lib = _lib.load()
             need = _lib.c_size_t()
@@ -257,17 +277,19 @@ class EmbeddingBank:
             )
             _lib.check(st, "isc_cosine_topk_workspace_bytes")
             ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
-            if len(self._workspaces) >= 4:  # bound what a bank pins: drop the oldest bucket
-                self._workspaces.pop(next(iter(self._workspaces)))
-            self._workspaces[key] = ws
+            if len(cache) >= 4:  # bound what a bank pins: drop the oldest bucket
+                cache.pop(next(iter(cache)))
+            cache[key] = ws
         return ws
 
     def _local_topk(
-        self, queries: Tensor, k: int, out: tuple[Tensor, Tensor, Tensor] | None = None
+        self, queries: Tensor, k: int, out: tuple[Tensor, Tensor, Tensor] | None = None, lane: int = -1,
+        stream: "torch.cuda.Stream | None" = None,
     ) -> tuple[Tensor, Tensor]:
         """Top-k of this rank's rows: `(float32 [Q, k], int64 [Q, k])` with GLOBAL row indices, final when the stream
         has run the call.  `out` optionally supplies the (scores, indices, status int32[4]) tensors to write into (the
-        exchange buffer of a sharded search)."""
+        exchange buffer of a sharded search); `lane` / `stream`: the workspace set and the stream of an asynchronous search
+        (default: the caller's current stream).  Tensors are allocated on the caller's stream whichever stream computes."""
         nq = queries.shape[0]
         if out is None:
             scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
@@ -275,13 +297,17 @@ class EmbeddingBank:
             status = torch.empty(4, dtype=torch.int32, device=self.device)
         else:
             scores, indices, status = out
-        ws = self._workspace(nq, k)
+        ws = self._workspace(nq, k, lane)
+        if stream is not None and out is None:
+            for t in (scores, indices, status):
+                t.record_stream(stream)
         lib = _lib.load()
         with torch.cuda.device(self.device):
             st = lib.isc_cosine_topk(
                 self._bank.data_ptr(), _lib.dtype_code(self.dtype), self.num_local_rows, self.dim, queries.data_ptr(),
                 nq, queries.stride(0), k, self.index_base, self._norm_bound.data_ptr(), scores.data_ptr(),
-                indices.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_handle(self.device),
+                indices.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(),
+                stream.cuda_stream if stream is not None else _lib.stream_handle(self.device),
             )
             _lib.check(st, "isc_cosine_topk")
         self.last_status = status
@@ -348,18 +374,41 @@ class EmbeddingBank:
         candidate buffers, [1] queries the first pass could not prove (searched again: one more matrix-core pass over the
         bank for all of them together), [3] queries answered by the exhaustive float64 sweep (about one bank sweep per
         four such queries: a bank with thousands of exact copies of a row pays this for queries that hit them).  `check` is accepted for compatibility with the
-        first version of this API and ignored.  Equivalent to `search_async(queries, k).result()`.
+        first version of this API and ignored.  Everything runs on the caller's current stream (a sharded bank's
+        exchange on the bank's exchange stream, ordered behind it).
         """
         del check
-        return self.search_async(queries, k).result()
+        return self._search(queries, k, lanes=False).result()
 
     def search_async(self, queries: Tensor, k: int = 10) -> SearchHandle:
         """`search` that returns as soon as everything is ENQUEUED; `handle.result()` orders the caller's current stream
-        behind the answer.  For a sharded bank the local kernels run on the caller's stream and the exchange
-        (all-gather + merge) on the bank's exchange stream, so a caller that issues search i + 1 before it resolves
-        handle i has exchange i running under the local kernels of i + 1.  Two exchange buffers alternate: at most two
-        searches of one bank should be unresolved at a time (a third waits, on the device, for the first one's
-        exchange)."""
+        behind the answer.  The local kernels of a search of up to 128 queries run on one of TWO streams of the bank,
+        alternately, each with its own workspace and ordered behind the caller's stream as it stands at the call (larger
+        searches stay on the caller's stream); a sharded bank's exchange (all-gather
+        + merge) runs on the bank's exchange stream.  A caller that issues search i + 1 before it resolves handle i
+        therefore has the short kernels at the end of search i (selection, exact re-score, the empty redo launches) and
+        its exchange running beside the first kernels of search i + 1 -- at a 1.25 M-row shard 20 - 25 us of a 320 us
+        search (`scripts/two_stream_probe.py`).  At most two searches of one bank should be unresolved at a time (a
+        third waits, on the device, for the first one)."""
+        return self._search(queries, k, lanes=True)
+
+    def _lane(self, cur: "torch.cuda.Stream", q: Tensor) -> tuple[int, "torch.cuda.Stream"]:
+        """The next of the two search streams, ordered behind everything the caller's stream holds so far."""
+        lane = self._lane_next
+        self._lane_next ^= 1
+        ls = _lane_streams(self.device)[lane]
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        ls.wait_event(ready)
+        q.record_stream(ls)  # (possibly a copy made on the caller's stream: keep it until the lane has read it)
+        return lane, ls
+
+    # Searches of more queries than this run on the caller's stream even when asynchronous: their kernels fill the GPU for
+    # milliseconds, there is nothing at their ends worth overlapping (measured: 1 757 -> 1 749 us at Q = 1024 on a 1.25 M-row
+    # shard), and two of them sharing the GPU would stretch each other's launches.
+    _LANE_MAX_QUERIES = 128
+
+    def _search(self, queries: Tensor, k: int, lanes: bool) -> SearchHandle:
         if not isinstance(k, int) or isinstance(k, bool):
             raise TypeError(f"k must be an int, got {type(k).__name__}")
         if k < 1:
@@ -368,13 +417,20 @@ class EmbeddingBank:
             raise ValueError(f"k must be <= {_lib.ISC_TOPK_MAX_K}, got {k}")
         q = self._prepare_queries(queries)
         nq = q.shape[0]
+        lanes = lanes and nq <= self._LANE_MAX_QUERIES
         if self.process_group is None:
             if k > self.num_local_rows:
                 raise ValueError(f"k={k} exceeds the bank size {self.num_local_rows}")
             if nq == 0:
                 return SearchHandle(torch.empty((0, k), dtype=torch.float32, device=self.device),
                                     torch.empty((0, k), dtype=torch.int64, device=self.device))
-            return SearchHandle(*self._local_topk(q, k))
+            if not (lanes and self.device.type == "cuda"):
+                return SearchHandle(*self._local_topk(q, k))
+            lane, ls = self._lane(torch.cuda.current_stream(self.device), q)
+            out_s, out_i = self._local_topk(q, k, lane=lane, stream=ls)
+            done = torch.cuda.Event()
+            done.record(ls)
+            return SearchHandle(out_s, out_i, done)
 
         # ---- sharded: local partial top-k -> ONE all-gather -> merge on every rank.  Every rank issues exactly one
         # collective per search whatever its shard holds, so the ranks cannot fall out of step.
@@ -393,17 +449,25 @@ class EmbeddingBank:
         on_gpu = self.device.type == "cuda"
         slot = self._slots[self._slot_next]
         self._slot_next ^= 1
+        lane, ls = -1, None
+        kl = min(k, self.num_local_rows)
         if on_gpu:
             cur = torch.cuda.current_stream(self.device)
+            if slot.buf is None or slot.buf.numel() < nbytes:
+                if slot.done is not None:  # the old buffer goes back to this stream's pool: nobody may still read it
+                    cur.wait_event(slot.done)
+                slot.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            if lanes and kl == k:  # (a shard with fewer rows than k is padded with tensor ops on the caller's stream)
+                lane, ls = self._lane(cur, q)
+                cur = ls  # the stream the local kernels run on
             if slot.done is not None:  # the exchange that last read this buffer (two searches ago)
                 cur.wait_event(slot.done)
-        if slot.buf is None or slot.buf.numel() < nbytes:
+        elif slot.buf is None or slot.buf.numel() < nbytes:
             slot.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         xbuf = slot.buf[:nbytes]
         part_s = xbuf[: 4 * nq * k].view(torch.float32).view(nq, k)
         part_i = xbuf[off_i:off_s].view(torch.int64).view(nq, k)
         status = xbuf[off_s:].view(torch.int32)
-        kl = min(k, self.num_local_rows)
         if kl < k:  # a shard with fewer rows than k: pad with entries that rank after every real candidate
             part_s.fill_(-math.inf)
             part_i.fill_(_PAD_INDEX)
@@ -413,7 +477,7 @@ class EmbeddingBank:
                 part_s[:, :kl] = s
                 part_i[:, :kl] = i
         else:
-            self._local_topk(q, k, out=(part_s, part_i, status))
+            self._local_topk(q, k, out=(part_s, part_i, status), lane=lane, stream=ls)
 
         def exchange() -> tuple[Tensor, Tensor, Tensor, Tensor]:
             gathered = self._all_gather_bytes(xbuf)

@@ -42,7 +42,7 @@ def _worker(rank: int, world: int, port: int, n: int, k: int, out_dir: str) -> N
             def _store(self, embeddings, normalize):  # keep the rows on the CPU
                 return embeddings.contiguous()
 
-            def _local_topk(self, queries, kk, out=None):  # `out`: the product's exchange buffer, filled in place
+            def _local_topk(self, queries, kk, out=None, lane=-1, stream=None):  # `out`: the product's exchange buffer, filled in place
                 s, i = search_oracle.cosine_topk(self._bank, queries, kk, index_base=self.index_base)
                 s, i = torch.from_numpy(s), torch.from_numpy(i)
                 if out is not None:
@@ -103,7 +103,7 @@ def _uneven_worker(rank: int, world: int, port: int, k: int, out_dir: str) -> No
             def _store(self, embeddings, normalize):
                 return embeddings.contiguous()
 
-            def _local_topk(self, queries, kk, out=None):  # `out`: the product's exchange buffer, filled in place
+            def _local_topk(self, queries, kk, out=None, lane=-1, stream=None):  # `out`: the product's exchange buffer, filled in place
                 s, i = search_oracle.cosine_topk(self._bank, queries, kk, index_base=self.index_base)
                 s, i = torch.from_numpy(s), torch.from_numpy(i)
                 if out is not None:
@@ -161,7 +161,7 @@ def _pipeline_worker(rank: int, world: int, port: int, n: int, k: int, out_dir: 
             def _store(self, embeddings, normalize):
                 return embeddings.contiguous()
 
-            def _local_topk(self, queries, kk, out=None):  # `out`: the product's exchange buffer, filled in place
+            def _local_topk(self, queries, kk, out=None, lane=-1, stream=None):  # `out`: the product's exchange buffer, filled in place
                 s, i = search_oracle.cosine_topk(self._bank, queries, kk, index_base=self.index_base)
                 s, i = torch.from_numpy(s), torch.from_numpy(i)
                 if out is not None:
