@@ -298,8 +298,11 @@ class EmbeddingBank:
         else:
             scores, indices, status = out
         ws = self._workspace(nq, k, lane)
-        if stream is not None and out is None:
-            for t in (scores, indices, status):
+        if stream is not None:
+            # every tensor this call touches was allocated on some other stream: tell the allocator the lane uses it, so
+            # that nothing handed back early (a dropped handle, a dropped bank, a workspace bucket pushed out of the cache)
+            # is given to somebody else before the lane's kernels have run
+            for t in (scores, indices, status, ws, self._bank, self._norm_bound):
                 t.record_stream(stream)
         lib = _lib.load()
         with torch.cuda.device(self.device):
@@ -496,6 +499,7 @@ class EmbeddingBank:
         local_done.record(cur)
         with torch.cuda.stream(self._xstream):
             self._xstream.wait_event(local_done)
+            xbuf.record_stream(self._xstream)  # (allocated on the caller's stream, read by the all-gather on this one)
             out_s, out_i, gathered, gstatus = exchange()
             done = torch.cuda.Event()
             done.record(self._xstream)
