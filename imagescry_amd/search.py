@@ -385,10 +385,10 @@ class EmbeddingBank:
 
     def search_async(self, queries: Tensor, k: int = 10) -> SearchHandle:
         """`search` that returns as soon as everything is ENQUEUED; `handle.result()` orders the caller's current stream
-        behind the answer.  The local kernels of a search of up to 128 queries run on one of TWO streams of the bank,
-        alternately, each with its own workspace and ordered behind the caller's stream as it stands at the call (larger
-        searches stay on the caller's stream); a sharded bank's exchange (all-gather
-        + merge) runs on the bank's exchange stream.  A caller that issues search i + 1 before it resolves handle i
+        behind the answer.  The local kernels of a search of up to 128 queries run on one of TWO library-owned streams
+        of the device, alternately -- the bank keeps a workspace for each -- ordered behind the caller's stream as it
+        stands at the call (larger searches stay on the caller's stream); a sharded bank's exchange (all-gather + merge)
+        runs on the bank's exchange stream.  A caller that issues search i + 1 before it resolves handle i
         therefore has the short kernels at the end of search i (selection, exact re-score, the empty redo launches) and
         its exchange running beside the first kernels of search i + 1 -- at a 1.25 M-row shard 20 - 25 us of a 320 us
         search (`scripts/two_stream_probe.py`).  At most two searches of one bank should be unresolved at a time (a
