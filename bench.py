@@ -97,7 +97,7 @@ def parse_args() -> argparse.Namespace:
     ap.add_argument("--no-overlap", action="store_true", help="--workload pipeline: one stream instead of two")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--no-sweep", action="store_true", help="skip the query-count sweep {1,16,64,256,1024} (N = 1 only)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the query-count / shard-size sweeps (N = 1 only)")
     return ap.parse_args()
 
 
@@ -151,6 +151,20 @@ def timed_steps(step, steps: int, warmup: int, world: int, device: torch.device)
         step()
     fence(world)
     return max_over_ranks(time.perf_counter() - t0, world, device)
+
+
+def bracketed_kernel_ms(step, steps: int, kernel_id: int) -> tuple[float, int]:
+    """(summed device ms inside the instrumented kernel, KERNEL launches) over `steps` more steps, run with the event
+    brackets on -- a loop of its own, after the loop `value` was timed in."""
+    torch.cuda.synchronize()
+    _lib.timing_enable(True)
+    _lib.timing_read(kernel_id)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    out = _lib.timing_read(kernel_id)
+    _lib.timing_enable(False)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ search
@@ -298,7 +312,7 @@ def search_roofline(rows: int, d: int, q: int, k: int, kernel_ms_per_step: float
 
 
 def query_sweep(bank: EmbeddingBank, rows: int, d: int, k: int, device: torch.device,
-                qs: tuple[int, ...] = (1, 16, 64, 256, 1024)) -> list[dict]:
+                qs: tuple[int, ...] = (1, 16, 64, 128, 256, 512, 1024)) -> list[dict]:
     """the same bank searched with 1 .. 1024 queries, so that the HBM-bound regime
     (few queries) is measured directly beside the MFMA-bound headline.  End-to-end time is taken with the per-kernel
     event brackets OFF; a second loop with them on gives the time inside k_dots_filter, and their difference is what a
@@ -356,6 +370,27 @@ def query_sweep(bank: EmbeddingBank, rows: int, d: int, k: int, device: torch.de
             "mfma_frac": r["mfma_frac"], "hbm_frac": r["hbm_frac"],
             "exact_pass_queries": int(bank.last_status[1].item()),
         })
+    return out
+
+
+def scaling_projection(sweep: list[dict], n: int) -> dict:
+    """A PROJECTION, not a measurement: what the 1 -> 8 GPU strong-scaling curve of the search would be if every rank ran
+    its shard as this one GPU runs a shard of that size (`q_sweep` rows with rows_per_gpu = n / G, searches issued as a
+    stream) and the exchange -- one all-gather of Q x k x 12 B per rank + the merge, on the bank's exchange stream under
+    the next search's local kernels -- cost nothing on the critical path.  The compute side only; the RCCL exchange has
+    not been timed.  The driver's SCALE run is the measurement."""
+    out = {"kind": "projection from single-GPU shard timings (exchange not included)", "rows": []}
+    for q in (64, 1024):
+        base = next((r for r in sweep if r["queries"] == q and r["rows_per_gpu"] == n), None)
+        for g in (1, 2, 4, 8):
+            r = next((r for r in sweep if r["queries"] == q and r["rows_per_gpu"] == n // g), None)
+            if r is None or base is None:
+                continue
+            ms = r["ms_per_search_streamed"]
+            out["rows"].append({"n_gpus": g, "queries": q, "ms_per_search": ms, "queries_per_s": round(q / ms * 1e3, 1),
+                                "speedup_vs_1": round(base["ms_per_search_streamed"] / ms, 3),
+                                "efficiency": round(base["ms_per_search_streamed"] / ms / g, 3),
+                                "hbm_frac_per_gpu": r["hbm_frac_streamed"], "mfma_frac_per_gpu": r["mfma_frac"]})
     return out
 
 
@@ -447,11 +482,16 @@ def bench_search(args: argparse.Namespace, rank: int, world: int, device: torch.
         if len(pending) > 1:
             pending.pop(0).result()
 
-    for _ in range(args.warmup):
-        step()
+    # `value` is timed with the per-kernel event brackets OFF; the time inside k_dots_filter comes from a SECOND loop of
+    # the same steps with them on (two extra event records per launch stretch a step by a fraction of a percent, which
+    # must not sit inside the number that is quoted).  scripts/trace_headline.sh reproduces `kernel_ms_per_step` from a
+    # rocprofv3 kernel trace of this same command by launch index (profiles/*_headline_trace.json).
+    seconds = timed_steps(step, args.steps, args.warmup, world, device)
+    while pending:
+        pending.pop(0).result()
     _lib.timing_enable(True)
     _lib.timing_read(_lib.ISC_KERNEL_DOTS_FILTER)
-    seconds = timed_steps(step, args.steps, 0, world, device)
+    seconds_bracketed = timed_steps(step, args.steps, 0, world, device)
     while pending:
         pending.pop(0).result()
     kernel_ms, launches = _lib.timing_read(_lib.ISC_KERNEL_DOTS_FILTER)
@@ -466,19 +506,28 @@ def bench_search(args: argparse.Namespace, rank: int, world: int, device: torch.
 
     rows = hi - lo
     roofline = search_roofline(rows, d, q, k, kernel_ms / args.steps, launches / args.steps)
+    roofline["ms_per_step_with_brackets"] = round(seconds_bracketed / args.steps * 1e3, 4)
+    roofline["search_calls_in_order"] = {"warmup": args.warmup, "timed": args.steps, "bracketed": args.steps, "selfcheck": 1}
     sweep = None
     if world == 1 and not args.no_sweep:
         sweep = query_sweep(bank, rows, d, k, device)
-        # the shard one GPU holds in the 8-GPU run of the same bank: what the north-star 70 %-of-HBM target is about
-        shard_rows = n // 8
-        if shard_rows >= 100_000:
+        # the shard one GPU holds when the same bank is split over 2 / 4 / 8 GPUs (8: what the north-star 70 %-of-HBM
+        # target is about): the per-GPU work of the strong-scaling curve, measured on this one GPU
+        for g in (2, 4, 8):
+            shard_rows = n // g
+            if shard_rows < 100_000:
+                continue
             small = EmbeddingBank(make_shard(0, shard_rows, d, device), dtype=torch.float16, normalize=False)
             torch.cuda.empty_cache()
-            shard_sweep = query_sweep(small, shard_rows, d, k, device, qs=(1, 16, 64, 1024))
-            for row in shard_sweep:  # what every rank of the 8-GPU search runs behind its all-gather
-                row["merge_us_g8"] = merge_us(small, row["queries"], k, device)
+            shard_sweep = query_sweep(small, shard_rows, d, k, device, qs=(1, 16, 64, 1024) if g == 8 else (64, 1024))
+            for row in shard_sweep:  # what every rank of the g-GPU search runs behind its all-gather
+                row["merge_us"] = merge_us(small, row["queries"], k, device, g=g)
+                row["shards"] = g
+                if g == 8:
+                    row["merge_us_g8"] = row["merge_us"]
             sweep += shard_sweep
             del small
+            torch.cuda.empty_cache()
     variants = None
     if world == 1 and not args.no_sweep and n >= 1_000_000:
         del bank
@@ -512,6 +561,7 @@ def bench_search(args: argparse.Namespace, rank: int, world: int, device: torch.
         "exact_pass_queries": status[1],  # queries the first pass could not prove (searched again on the device)
         "exhaustive_pass_queries": status[3],
         "q_sweep": sweep,
+        "scaling_projection": scaling_projection(sweep, n) if sweep else None,
         "bank_variants": variants,
         "_bank": bank, "_queries": queries,
     }
@@ -559,13 +609,8 @@ def bench_encode(args: argparse.Namespace, rank: int, world: int, device: torch.
     def step() -> None:
         model.predict_step(batch)
 
-    for _ in range(warmup):
-        step()
-    _lib.timing_enable(True)
-    _lib.timing_read(_lib.ISC_KERNEL_CONV)
-    seconds = timed_steps(step, steps, 0, world if collective_timing else 1, device)
-    kernel_ms, launches = _lib.timing_read(_lib.ISC_KERNEL_CONV)
-    _lib.timing_enable(False)
+    seconds = timed_steps(step, steps, warmup, world if collective_timing else 1, device)  # brackets off
+    kernel_ms, launches = bracketed_kernel_ms(step, steps, _lib.ISC_KERNEL_CONV)
     flops = float(resnet50.conv_flops(b, 224, 224))
     tflops = flops * steps / (kernel_ms / 1e3) / 1e12
     ranks = world if collective_timing else 1
@@ -606,13 +651,8 @@ def bench_encode_vit(args: argparse.Namespace, device: torch.device, steps: int,
     images = torch.randint(0, 256, (b, 3, 224, 224), dtype=torch.uint8,
                            generator=torch.Generator().manual_seed(SEED)).to(device)
     batch = ImageBatch(indices=torch.arange(b, device=device), images=images)
-    for _ in range(warmup):
-        model.predict_step(batch)
-    _lib.timing_enable(True)
-    _lib.timing_read(_lib.ISC_KERNEL_GEMM_F16)
-    seconds = timed_steps(lambda: model.predict_step(batch), steps, 0, 1, device)
-    kernel_ms, launches = _lib.timing_read(_lib.ISC_KERNEL_GEMM_F16)
-    _lib.timing_enable(False)
+    seconds = timed_steps(lambda: model.predict_step(batch), steps, warmup, 1, device)  # brackets off
+    kernel_ms, launches = bracketed_kernel_ms(lambda: model.predict_step(batch), steps, _lib.ISC_KERNEL_GEMM_F16)
     cfg = vit.VIT_B16
     t, d = cfg.tokens, cfg.dim
     gemm_flops = float(b) * (2 * (t - 1) * d * 3 * cfg.patch_size**2
@@ -653,13 +693,8 @@ def bench_encode_efficientnet(args: argparse.Namespace, device: torch.device, st
     images = torch.randint(0, 256, (b, 3, 224, 224), dtype=torch.uint8,
                            generator=torch.Generator().manual_seed(SEED)).to(device)
     batch = ImageBatch(indices=torch.arange(b, device=device), images=images)
-    for _ in range(warmup):
-        model.predict_step(batch)
-    _lib.timing_enable(True)
-    _lib.timing_read(_lib.ISC_KERNEL_CONV)
-    seconds = timed_steps(lambda: model.predict_step(batch), steps, 0, 1, device)
-    kernel_ms, launches = _lib.timing_read(_lib.ISC_KERNEL_CONV)
-    _lib.timing_enable(False)
+    seconds = timed_steps(lambda: model.predict_step(batch), steps, warmup, 1, device)  # brackets off
+    kernel_ms, launches = bracketed_kernel_ms(lambda: model.predict_step(batch), steps, _lib.ISC_KERNEL_CONV)
     flops = float(efficientnet.conv_flops("s", b, 224, 224))
     tflops = flops * steps / (kernel_ms / 1e3) / 1e12
     eff_traffic, eff_traffic_src, eff_ratio = measured_encoder_traffic("efficientnet_s", b)
@@ -809,6 +844,8 @@ def main() -> None:
                 line[key] = primary[key]
         if primary.get("q_sweep"):
             line["q_sweep"] = primary["q_sweep"]
+        if primary.get("scaling_projection"):
+            line["scaling_projection"] = primary["scaling_projection"]
         if primary.get("bank_variants"):
             line["bank_variants"] = primary["bank_variants"]
         if world == 1 and not args.no_cpu_baseline:

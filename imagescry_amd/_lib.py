@@ -27,7 +27,7 @@ ISC_ACT_RESIDUAL_AFTER = 0x100
 ISC_TOPK_MAX_K = 120
 ISC_SEARCH_MAX_D = 8192
 ISC_SEARCH_PASS_QUERIES = 1024  # queries per pass of isc_cosine_topk (the workspace is sized for one pass)
-ISC_ABI_VERSION = 3
+ISC_ABI_VERSION = 4
 ISC_BUILD_ABLATION = 1
 ISC_GEMM_A_PACKED, ISC_GEMM_W_PACKED, ISC_GEMM_OUT_PACKED, ISC_GEMM_TILE_256, ISC_GEMM_TILE_128 = 1, 2, 4, 8, 16
 ISC_KERNEL_DOTS_FILTER, ISC_KERNEL_CONV, ISC_KERNEL_GEMM_F16 = 0, 1, 2
@@ -132,13 +132,13 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "isc_cosine_topk_workspace_bytes": (c_int, [c_int, c_int64, c_int, c_int, c_int, POINTER(c_size_t)]),
     "isc_cosine_topk": (
         c_int,
-        [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p,
+        [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p,
          c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     "isc_cosine_topk_exhaustive_workspace_bytes": (c_int, [c_int, c_int64, c_int, c_int, c_int, POINTER(c_size_t)]),
     "isc_cosine_topk_exhaustive": (
         c_int,
-        [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p,
+        [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p,
          c_void_p, c_size_t, c_void_p],
     ),
     "isc_topk_merge": (

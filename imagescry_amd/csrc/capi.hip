@@ -49,7 +49,11 @@ namespace {
 struct TimingState {
     std::mutex mu;
     bool enabled = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[ISC_KERNEL_COUNT];
+    struct Bracket {
+        hipEvent_t first, second;
+        int kernels;  // kernel launches inside the bracket (a convolution may run as two: whole rounds + half-tile remainder)
+    };
+    std::vector<Bracket> pending[ISC_KERNEL_COUNT];
     std::vector<hipEvent_t> pool;
     hipEvent_t open_begin[ISC_KERNEL_COUNT] = {};
 };
@@ -79,7 +83,7 @@ void isc_timing_begin(int kernel_id, hipStream_t stream) {
     t.open_begin[kernel_id] = e;
 }
 
-void isc_timing_end(int kernel_id, hipStream_t stream) {
+void isc_timing_end(int kernel_id, hipStream_t stream, int kernels) {
     TimingState& t = timing();
     if (!t.enabled) return;
     std::lock_guard<std::mutex> lock(t.mu);
@@ -92,7 +96,7 @@ void isc_timing_end(int kernel_id, hipStream_t stream) {
         return;
     }
     (void)hipEventRecord(e, stream);
-    t.pending[kernel_id].emplace_back(b, e);
+    t.pending[kernel_id].push_back({b, e, kernels > 0 ? kernels : 1});
 }
 
 extern "C" int isc_timing_enable(int enable) {
@@ -112,7 +116,7 @@ extern "C" int isc_timing_read(int kernel_id, double* total_ms, int* launches) {
         float ms = 0.f;
         if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
             sum += ms;
-            ++n;
+            n += pr.kernels;
         }
         t.pool.push_back(pr.first);
         t.pool.push_back(pr.second);

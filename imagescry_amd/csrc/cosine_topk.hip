@@ -243,8 +243,10 @@ Workspace carve(const Plan& p, int ks, int64_t n, int k, void* base) {
 // Per-query state reset and query packing in one launch.
 // queries row-major [q][ldq] -> packed [qtile][K step][tnq rows][128 B]; rows >= q and columns >= d are zero.
 // One thread per 16-byte chunk; the first qpad threads also reset the per-query words.
-template <typename T>
-__global__ __launch_bounds__(256) void k_prep(const T* __restrict__ queries, int64_t ldq, int q, int d, int ks, int qpad,
+// TQ = element type of the caller's queries: they are rounded to the bank type T while they are packed (float32 -> fp16:
+// v_cvt_f16_f32, round to nearest even = `Tensor.to(float16)`; fp16 -> float32 is exact), so no cast kernel runs in front.
+template <typename T, typename TQ>
+__global__ __launch_bounds__(256) void k_prep(const TQ* __restrict__ queries, int64_t ldq, int q, int d, int ks, int qpad,
                                               int tnq, unsigned char* __restrict__ packed, float* __restrict__ tau,
                                               int32_t* __restrict__ carry_n, int32_t* __restrict__ qcount,
                                               int32_t* __restrict__ qflag, int32_t* __restrict__ redo_count,
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void k_prep(const T* __restrict__ queries, int
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int e = (kstep * 8 + c) * PER + j;
-        v[j] = (qrow < q && e < d) ? queries[(int64_t)qrow * ldq + e] : (T)0.f;
+        v[j] = (qrow < q && e < d) ? (T)queries[(int64_t)qrow * ldq + e] : (T)0.f;
     }
     *reinterpret_cast<uint4*>(packed + (size_t)i * 16) = *reinterpret_cast<const uint4*>(v);
 }
@@ -1806,7 +1808,7 @@ void for_each_segment(const Level& l, const Plan& p, F&& launch) {
     }
 }
 
-template <typename T>
+template <typename T, typename TQ>
 int run(const void* bank, int64_t n, int d, const void* queries, int q_total, int64_t ldq, int k, int64_t index_base,
         const float* norm_bound, float* out_s, int64_t* out_i, int32_t* status, void* ws_base, hipStream_t stream) {
     const Plan p = make_plan(n, q_total, k);
@@ -1823,11 +1825,11 @@ int run(const void* bank, int64_t n, int d, const void* queries, int q_total, in
     const IscPerm pm = isc_make_perm(n);
     for (int q0 = 0; q0 < q_total; q0 += p.qb) {
         const int q = q_total - q0 < p.qb ? q_total - q0 : p.qb;
-        const T* qptr = static_cast<const T*>(queries) + (int64_t)q0 * ldq;
+        const TQ* qptr = static_cast<const TQ*>(queries) + (int64_t)q0 * ldq;
         float* os = out_s + (size_t)q0 * k;
         int64_t* oi = out_i + (size_t)q0 * k;
         const bool spec_all = q <= SMALL_Q;  // few queries: fetch every list blindly (one round trip); see wg_select
-        hipLaunchKernelGGL(k_prep<T>, dim3(isc_ceil_div(p.qpad * ksteps * 8, 256)), dim3(256), 0, stream, qptr, ldq, q,
+        hipLaunchKernelGGL((k_prep<T, TQ>), dim3(isc_ceil_div(p.qpad * ksteps * 8, 256)), dim3(256), 0, stream, qptr, ldq, q,
                            d, ksteps, p.qpad, p.tnq, w.qpacked, w.tau, w.carry_n, w.qcount, w.qflag,
                            w.exact.redo_count, w.exact.done, w.r_count, w.tau2, w.qcount2, w.qflag2, status,
                            q0 == 0 ? 1 : 0);
@@ -1885,8 +1887,9 @@ int run(const void* bank, int64_t n, int d, const void* queries, int q_total, in
                                pm, index_base, w.r_count, w.r_list, w.qcount2, w.qflag2, w.qlist, os, oi,
                                w.exact.redo_count, w.exact.redo_list, status);
         }
-        const int st = isc_exact_launch(sizeof(T) == 2 ? ISC_F16 : ISC_F32, bank, n, d, qptr, ldq, k, index_base,
-                                        w.exact, os, oi, status, stream);
+        const int st = isc_exact_launch(sizeof(T) == 2 ? ISC_F16 : ISC_F32, bank, n, d, qptr,
+                                        sizeof(TQ) == 2 ? ISC_F16 : ISC_F32, ldq, k, index_base, w.exact, os, oi, status,
+                                        stream);
         if (st != ISC_OK) return st;
     }
     return isc_launch_status();
@@ -1912,11 +1915,12 @@ extern "C" int isc_cosine_topk_workspace_bytes(int dtype, int64_t N, int D, int 
     return ISC_OK;
 }
 
-extern "C" int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, const void* queries, int Q, int64_t ldq,
-                               int k, int64_t index_base, const float* norm_bound, float* out_scores,
+extern "C" int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, const void* queries, int q_dtype, int Q,
+                               int64_t ldq, int k, int64_t index_base, const float* norm_bound, float* out_scores,
                                int64_t* out_indices, int32_t* status, void* workspace, size_t workspace_bytes,
                                void* stream) {
     ISC_REQUIRE(bank && queries && out_scores && out_indices && status);
+    ISC_REQUIRE(q_dtype == ISC_F16 || q_dtype == ISC_F32);
     const int st = check_args(dtype, N, D, Q, k);
     if (st != ISC_OK) return st;
     ISC_REQUIRE(ldq >= D);
@@ -1924,9 +1928,14 @@ extern "C" int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, co
     size_t need = 0;
     isc_cosine_topk_workspace_bytes(dtype, N, D, Q, k, &need);
     if (!workspace || workspace_bytes < need) return ISC_ERR_WORKSPACE;
-    if (dtype == ISC_F16)
-        return run<_Float16>(bank, N, D, queries, Q, ldq, k, index_base, norm_bound, out_scores, out_indices, status,
-                             workspace, isc_stream(stream));
-    return run<float>(bank, N, D, queries, Q, ldq, k, index_base, norm_bound, out_scores, out_indices, status,
-                      workspace, isc_stream(stream));
+#define ISC_RUN(T_, TQ_)                                                                                          \
+    return run<T_, TQ_>(bank, N, D, queries, Q, ldq, k, index_base, norm_bound, out_scores, out_indices, status, \
+                        workspace, isc_stream(stream))
+    if (dtype == ISC_F16) {
+        if (q_dtype == ISC_F16) ISC_RUN(_Float16, _Float16);
+        ISC_RUN(_Float16, float);
+    }
+    if (q_dtype == ISC_F16) ISC_RUN(float, _Float16);
+    ISC_RUN(float, float);
+#undef ISC_RUN
 }

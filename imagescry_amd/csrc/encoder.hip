@@ -1082,7 +1082,7 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
             else if (narrow) hipLaunchKernelGGL((k_conv_f32<64, 128, false, true>), g2, block, 0, s, q, halves);
             else if (tap4) hipLaunchKernelGGL((k_conv_f32<128, 64, true, true>), g2, block, 0, s, q, halves);
             else hipLaunchKernelGGL((k_conv_f32<128, 64, false, true>), g2, block, 0, s, q, halves);
-            isc_timing_end(ISC_KERNEL_CONV, s);
+            isc_timing_end(ISC_KERNEL_CONV, s, rounds > 0 ? 2 : 1);
             return isc_launch_status();
         }
     }

@@ -35,9 +35,11 @@ static inline int isc_device_cus() {
     return cus;
 }
 
-// device-time bracket around one kernel launch (no-ops unless isc_timing_enable(1); defined in capi.hip)
+// device-time bracket around the launch(es) of one instrumented kernel (no-ops unless isc_timing_enable(1); defined in
+// capi.hip).  `kernels` = how many launches of that kernel the bracket holds: isc_timing_read reports KERNEL launches, the
+// unit a rocprofv3 kernel trace counts in.
 void isc_timing_begin(int kernel_id, hipStream_t stream);
-void isc_timing_end(int kernel_id, hipStream_t stream);
+void isc_timing_end(int kernel_id, hipStream_t stream, int kernels = 1);
 
 template <typename T>
 static inline T isc_ceil_div(T a, T b) {

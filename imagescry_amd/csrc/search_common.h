@@ -83,7 +83,8 @@ struct IscExactWs {
 size_t isc_exact_ws_bytes(int64_t n, int q, int k);
 IscExactWs isc_exact_ws_carve(void* base, int64_t n, int q, int k);
 // enqueue k_exact: searches queries redo_list[0 .. *redo_count) and writes rows redo_list[i] of out_s / out_i
-// (leading dimension k).  `q_stride_rows` queries of `dtype` at `queries` with leading dimension ldq.
-int isc_exact_launch(int dtype, const void* bank, int64_t n, int d, const void* queries, int64_t ldq, int k,
+// (leading dimension k).  Queries of `q_dtype` at `queries` with leading dimension ldq (elements of q_dtype); every
+// element is rounded to the bank's `dtype` first, as isc_cosine_topk does when it packs them.
+int isc_exact_launch(int dtype, const void* bank, int64_t n, int d, const void* queries, int q_dtype, int64_t ldq, int k,
                      int64_t index_base, const IscExactWs& ws, float* out_s, int64_t* out_i, int32_t* status,
                      hipStream_t stream);

@@ -65,8 +65,8 @@ __device__ __forceinline__ double group8_sum(double v) {  // over the 8 lanes th
 // lists by one wave per query) and writes the result rows.
 template <typename T, int GQ>
 __global__ __launch_bounds__(EX_THREADS) void k_exact(const unsigned char* __restrict__ bank, int ks, IscPerm pm,
-                                                      int ntiles, int tiles_per_chunk, const T* __restrict__ queries,
-                                                      int64_t ldq, int d, int k, int64_t index_base,
+                                                      int ntiles, int tiles_per_chunk, const void* __restrict__ queries,
+                                                      int q_f32, int64_t ldq, int d, int k, int64_t index_base,
                                                       const int32_t* __restrict__ redo_count,
                                                       const int32_t* __restrict__ redo_list,
                                                       unsigned long long* __restrict__ part, int32_t* __restrict__ done,
@@ -94,8 +94,14 @@ __global__ __launch_bounds__(EX_THREADS) void k_exact(const unsigned char* __res
         __syncthreads();  // the previous group's lists have been merged
         for (int g = 0; g < GQ; ++g) {
             const int qi = g < gn ? redo_list[g0 + g] : 0;
-            const T* qp = queries + (int64_t)qi * ldq;
-            for (int e = tid; e < dp; e += EX_THREADS) qd[(size_t)g * dp + e] = (g < gn && e < d) ? (double)qp[e] : 0.0;
+            // the caller's query elements (fp16 or float32, `q_f32`) rounded to the bank type first, as k_prep packs them
+            const float* qp32 = static_cast<const float*>(queries) + (int64_t)qi * ldq;
+            const _Float16* qp16 = static_cast<const _Float16*>(queries) + (int64_t)qi * ldq;
+            for (int e = tid; e < dp; e += EX_THREADS) {
+                double v = 0.0;
+                if (g < gn && e < d) v = (double)(float)(T)(q_f32 ? qp32[e] : (float)qp16[e]);
+                qd[(size_t)g * dp + e] = v;
+            }
         }
         for (int i = tid; i < GQ * EX_WAVES * k; i += EX_THREADS) lists[i] = 0ull;
         __syncthreads();
@@ -292,7 +298,7 @@ int ex_check(int dtype, int64_t n, int d, int q, int k) {
 }
 
 template <typename T, int GQ>
-int launch_exact(const void* bank, int64_t n, int d, const void* queries, int64_t ldq, int k, int64_t index_base,
+int launch_exact(const void* bank, int64_t n, int d, const void* queries, int q_f32, int64_t ldq, int k, int64_t index_base,
                   const IscExactWs& ws, float* out_s, int64_t* out_i, int32_t* status, hipStream_t stream) {
     const int ks = isc_ksteps(d, (int)sizeof(T));
     const int dp = ks * (ISC_KSTEP_BYTES / (int)sizeof(T));
@@ -314,18 +320,18 @@ int launch_exact(const void* bank, int64_t n, int d, const void* queries, int64_
     }
     hipLaunchKernelGGL((k_exact<T, GQ>), dim3(ws.chunks), dim3(EX_THREADS), lds, stream,
                        static_cast<const unsigned char*>(bank), ks, isc_make_perm(n), ntiles, ws.tiles_per_chunk,
-                       static_cast<const T*>(queries), ldq, d, k, index_base, ws.redo_count, ws.redo_list, ws.part,
+                       queries, q_f32, ldq, d, k, index_base, ws.redo_count, ws.redo_list, ws.part,
                        ws.done, out_s, out_i, status);
     return ISC_OK;
 }
 
 template <typename T>
-int launch_exact_t(const void* bank, int64_t n, int d, const void* queries, int64_t ldq, int k, int64_t index_base,
+int launch_exact_t(const void* bank, int64_t n, int d, const void* queries, int q_f32, int64_t ldq, int k, int64_t index_base,
                     const IscExactWs& ws, float* out_s, int64_t* out_i, int32_t* status, hipStream_t stream) {
     const int dp = isc_ksteps(d, (int)sizeof(T)) * (ISC_KSTEP_BYTES / (int)sizeof(T));
-    if (dp <= 3072) return launch_exact<T, 4>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream);
-    if (dp <= 6144) return launch_exact<T, 2>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream);
-    return launch_exact<T, 1>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream);
+    if (dp <= 3072) return launch_exact<T, 4>(bank, n, d, queries, q_f32, ldq, k, index_base, ws, out_s, out_i, status, stream);
+    if (dp <= 6144) return launch_exact<T, 2>(bank, n, d, queries, q_f32, ldq, k, index_base, ws, out_s, out_i, status, stream);
+    return launch_exact<T, 1>(bank, n, d, queries, q_f32, ldq, k, index_base, ws, out_s, out_i, status, stream);
 }
 
 }  // namespace
@@ -348,12 +354,13 @@ IscExactWs isc_exact_ws_carve(void* base, int64_t n, int q, int k) {
     return w;
 }
 
-int isc_exact_launch(int dtype, const void* bank, int64_t n, int d, const void* queries, int64_t ldq, int k,
+int isc_exact_launch(int dtype, const void* bank, int64_t n, int d, const void* queries, int q_dtype, int64_t ldq, int k,
                      int64_t index_base, const IscExactWs& ws, float* out_s, int64_t* out_i, int32_t* status,
                      hipStream_t stream) {
+    const int qf = q_dtype == ISC_F32 ? 1 : 0;
     const int st = dtype == ISC_F16
-                       ? launch_exact_t<_Float16>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream)
-                       : launch_exact_t<float>(bank, n, d, queries, ldq, k, index_base, ws, out_s, out_i, status, stream);
+                       ? launch_exact_t<_Float16>(bank, n, d, queries, qf, ldq, k, index_base, ws, out_s, out_i, status, stream)
+                       : launch_exact_t<float>(bank, n, d, queries, qf, ldq, k, index_base, ws, out_s, out_i, status, stream);
     return st != ISC_OK ? st : isc_launch_status();
 }
 
@@ -381,10 +388,11 @@ extern "C" int isc_cosine_topk_exhaustive_workspace_bytes(int dtype, int64_t N, 
     return ISC_OK;
 }
 
-extern "C" int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N, int D, const void* queries, int Q,
-                                          int64_t ldq, int k, int64_t index_base, float* out_scores,
+extern "C" int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N, int D, const void* queries, int q_dtype,
+                                          int Q, int64_t ldq, int k, int64_t index_base, float* out_scores,
                                           int64_t* out_indices, void* workspace, size_t workspace_bytes, void* stream) {
     ISC_REQUIRE(bank && queries && out_scores && out_indices);
+    ISC_REQUIRE(q_dtype == ISC_F16 || q_dtype == ISC_F32);
     const int st = ex_check(dtype, N, D, Q, k);
     if (st != ISC_OK) return st;
     ISC_REQUIRE(ldq >= D);
@@ -393,13 +401,13 @@ extern "C" int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N
     if (!isc_aligned(workspace, 256)) return ISC_ERR_ALIGNMENT;
     const IscExactWs ws = isc_exact_ws_carve(workspace, N, qb, k);
     hipStream_t s = isc_stream(stream);
-    const size_t esz = dtype == ISC_F16 ? 2 : 4;
+    const size_t esz = q_dtype == ISC_F16 ? 2 : 4;
     for (int q0 = 0; q0 < Q; q0 += qb) {
         const int q = Q - q0 < qb ? Q - q0 : qb;
         hipLaunchKernelGGL(k_list_all, dim3(isc_ceil_div(q, 256)), dim3(256), 0, s, ws.redo_count, ws.redo_list, ws.done,
                            q);
         const int st2 = isc_exact_launch(dtype, bank, N, D, static_cast<const char*>(queries) + (size_t)q0 * ldq * esz,
-                                         ldq, k, index_base, ws, out_scores + (size_t)q0 * k,
+                                         q_dtype, ldq, k, index_base, ws, out_scores + (size_t)q0 * k,
                                          out_indices + (size_t)q0 * k, nullptr, s);
         if (st2 != ISC_OK) return st2;
     }

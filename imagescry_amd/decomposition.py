@@ -31,13 +31,16 @@ class PCA:
         num_features: int = 0,
         num_components: int = 0,
     ) -> None:
-        # reference: decomposition.py:46-52
+        # The same three argument checks as the reference constructor (decomposition.py:46-52: ValueError for each), worded
+        # here; callers match on the exception type.
         if min_num_components < 1:
-            raise ValueError(f"min_num_components must be at least 1, got {min_num_components}")
+            raise ValueError(f"PCA needs min_num_components >= 1 (got {min_num_components})")
         if max_num_components is not None and max_num_components < min_num_components:
-            raise ValueError(f"max_num_components must be at least {min_num_components}, got {max_num_components}")
-        if min_explained_variance < 0.0 or min_explained_variance > 1.0:
-            raise ValueError(f"min_explained_variance must be between 0.0 and 1.0, got {min_explained_variance}")
+            raise ValueError(
+                f"max_num_components={max_num_components} is below min_num_components={min_num_components}"
+            )
+        if not 0.0 <= min_explained_variance <= 1.0:
+            raise ValueError(f"min_explained_variance is a fraction in [0, 1] (got {min_explained_variance})")
         self.min_num_components = min_num_components
         self.max_num_components = max_num_components
         self.min_explained_variance = min_explained_variance
@@ -56,9 +59,9 @@ class PCA:
         self._packed: tuple[Tensor, Tensor] | None = None  # (mean [Fpad], weights [Kpad, Fpad]) on the device
 
     def __repr__(self) -> str:
-        num_features = self.num_features if self.fitted else "not fitted"
-        num_components = self.num_components if self.fitted else "not fitted"
-        return f"{self.__class__.__name__}(num_features={num_features}, num_components={num_components})"
+        # contract string: the reference prints the two sizes, or "not fitted" for both (decomposition.py:73-76)
+        shown = (self.num_features, self.num_components) if self.fitted else ("not fitted", "not fitted")
+        return f"{type(self).__name__}(num_features={shown[0]}, num_components={shown[1]})"
 
     # ------------------------------------------------------------------ fit (device + an F x F eigenproblem)
     GRAM_CHUNK_ROWS = 32768  # samples per Gram launch: each chunk's sum is float32, the chunks are added in float64
@@ -66,6 +69,7 @@ class PCA:
     def fit(self, x: Tensor) -> "PCA":
         """Principal axes of the centred (not scaled) rows and how many of them the constructor arguments ask for.
 
+        `x` is used as float32 (a float64 input is rounded once, and `feature_means` is float32 whatever the input type).
         The reference centres `x` and takes `torch.linalg.svd` of the `[N, F]` matrix on the host
         (decomposition.py:118-146).  Here everything N-sized runs on the GPU, in three kernels: per-feature sums in
         float64 (`isc_feature_sums`), the centred rows written transposed chunk by chunk (`isc_center_transpose`), and
@@ -81,8 +85,14 @@ class PCA:
         num_samples, num_features = x.shape
         if num_samples < 2:
             raise ValueError(f"num_samples must be at least 2, got {num_samples}")
-        if x.device.type != "cuda" and self._device.type == "cuda":
-            x = x.to(self._device)  # a host tensor handed to a model that lives on the GPU
+        if x.device.type != "cuda":
+            # The reference is always called as `PCA(...).fit(host_samples)` (decomposition.py:94-148): a host tensor goes
+            # to the model's device, or -- for a model that has not been placed yet -- to the current HIP device.  That is a
+            # copy, not a CPU computation: without a HIP device the call raises below.
+            if self._device.type == "cuda":
+                x = x.to(self._device)
+            elif torch.cuda.is_available():
+                x = x.to(torch.device("cuda", torch.cuda.current_device()))
         _lib.require_device(x, "x")  # no CPU fallback
         dev = x.device
         lib = _lib.load()
@@ -122,8 +132,12 @@ class PCA:
         lead = evecs.abs().argmax(dim=0)
         evecs = evecs * torch.sign(evecs[lead, torch.arange(f)]).masked_fill_(evecs[lead, torch.arange(f)] == 0, 1.0)
         rank = min(n, f)  # the reference's SVD returns min(N, F) singular values
-        eigenvalues = evals[:rank] / (n - 1)
-        explained = eigenvalues / eigenvalues.sum()
+        # From here on in float32, as the reference computes it (s ** 2 / (n - 1), its sum, the ratio and the cumulative sum
+        # are all float32 tensors there, decomposition.py:124-128): with a threshold near 1 the count of components depends
+        # on the rounding of the tail of that float32 cumsum, so the same arithmetic is used.  Accuracy floor: the Gram
+        # route squares the condition number, eigenvalues below ~1e-7 of the largest are rounding noise (clamped at 0).
+        eigenvalues = (evals[:rank] / (n - 1)).float()
+        explained = eigenvalues / torch.sum(eigenvalues)
         cumulative = torch.cumsum(explained, dim=0)
         needed = int((cumulative < self.min_explained_variance).sum().item()) + 1
         num_components = max(self.min_num_components, needed)
@@ -133,7 +147,7 @@ class PCA:
         self._num_features = f
         self._num_components = num_components
         self.feature_means = mean.reshape(1, f)
-        self.explained_variance = explained.float().to(dev)
+        self.explained_variance = explained.to(dev)
         self.component_vectors = evecs[:, :num_components].float().contiguous().to(dev)
         self._fitted = True
         self.hparams.update({"num_features": f, "num_components": num_components})

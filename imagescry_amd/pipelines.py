@@ -115,11 +115,14 @@ class EmbedSearchPipeline:
         self.exact_pass_queries: Tensor | None = None
 
     def _queries(self, emb: EmbeddingBatch) -> Tensor:
-        """This rank's flat vectors in the bank dtype -- gathered over the ranks of a sharded bank."""
-        q = emb.get_flat_vectors().to(self.bank.dtype).contiguous()
+        """This rank's flat vectors -- gathered over the ranks of a sharded bank.  One GPU: exactly what the reference's
+        `get_flat_vectors` returns (float32, data.py:112-118); `isc_cosine_topk` rounds them to the bank dtype while it
+        packs them (`q_dtype`), no cast kernel runs.  Sharded: they are cast to the bank dtype BEFORE the all-gather, which
+        halves the bytes every rank sends over xGMI for an fp16 bank (the search would round them to it anyway)."""
         group = self.bank.process_group
         if group is None:
-            return q
+            return emb.get_flat_vectors()
+        q = emb.get_flat_vectors().to(self.bank.dtype).contiguous()
         world = dist.get_world_size(group)
         on_host = dist.get_backend(group) == "gloo" and q.device.type != "cpu"
         src = q.cpu() if on_host else q
@@ -140,14 +143,24 @@ class EmbedSearchPipeline:
         Streams (overlap=True): batch i is encoded, and its embeddings all-gathered, on the encode stream; its local
         search runs on the search stream behind an event; for a sharded bank the exchange of the partial results
         (all-gather + merge) runs on the bank's own exchange stream (`EmbeddingBank.search_async`), i.e. under the
-        local search of batch i + 1 and the encode of batch i + 2.  The handles are resolved once, after the loop."""
+        local search of batch i + 1 and the encode of batch i + 2.  Handle i - 1 is resolved right after search i has been
+        enqueued (an event wait on the caller's stream, no host synchronisation), so at most two searches are unresolved
+        and device memory does not grow with the number of batches (a handle pins its gathered exchange buffers)."""
         device = self.embedding_model.device
         use_streams = self.overlap and device.type == "cuda"
         if use_streams:
             enc_stream, search_stream = torch.cuda.Stream(device), torch.cuda.Stream(device)
             enc_stream.wait_stream(torch.cuda.current_stream(device))
             search_stream.wait_stream(torch.cuda.current_stream(device))
-        pending: list[tuple[Tensor, int, SearchHandle]] = []
+        results: list[SearchResult] = []
+        pending: tuple[Tensor, int, SearchHandle] | None = None
+
+        def resolve(item: tuple[Tensor, int, SearchHandle]) -> None:
+            indices, rows, handle = item
+            scores, neighbours = handle.result()  # orders the current stream behind the search / exchange stream
+            results.append(SearchResult(indices=indices, scores=self._own_rows(scores, rows),
+                                        neighbours=self._own_rows(neighbours, rows)))
+
         for batch in dataloader:
             batch = batch.to(device)
             if use_streams:
@@ -170,15 +183,14 @@ class EmbedSearchPipeline:
                 handle = self.bank.search_async(q, self.k)
                 if self.bank.process_group is not None:
                     handle.result()  # one stream: exchange i before search i + 1
-            pending.append((batch.indices, rows, handle))
+            if pending is not None:
+                resolve(pending)
+            pending = (batch.indices, rows, handle)
         if use_streams:
             torch.cuda.current_stream(device).wait_stream(enc_stream)
             torch.cuda.current_stream(device).wait_stream(search_stream)
-        results = []
-        for indices, rows, handle in pending:
-            scores, neighbours = handle.result()  # orders the current stream behind the exchange stream
-            results.append(SearchResult(indices=indices, scores=self._own_rows(scores, rows),
-                                        neighbours=self._own_rows(neighbours, rows)))
+        if pending is not None:
+            resolve(pending)
         self.exact_pass_queries = self._exact_pass_counter()
         return results
 

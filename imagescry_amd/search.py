@@ -72,24 +72,26 @@ class SearchHandle:
     recorded behind the merge has fired.  `result()` orders the caller's current stream behind that event (no host
     synchronisation) and returns `(scores, indices)`."""
 
-    __slots__ = ("_scores", "_indices", "_event", "_keep", "gathered_status")
+    __slots__ = ("_scores", "_indices", "_event", "gathered_status")
 
     def __init__(self, scores: Tensor, indices: Tensor, event: "torch.cuda.Event | None" = None,
-                 keep: Tensor | None = None, gathered_status: Tensor | None = None) -> None:
+                 gathered_status: Tensor | None = None) -> None:
         self._scores = scores
         self._indices = indices
         self._event = event
-        self._keep = keep  # the gathered exchange buffers (`gathered_status` is a view into them)
+        # [G, 4] diagnostics of every shard: a view into the gathered exchange buffers, which it keeps alive (they were
+        # allocated on the exchange stream and are read only there, so nothing else has to hold them)
         self.gathered_status = gathered_status
 
     def result(self) -> tuple[Tensor, Tensor]:
+        """May be called more than once and from different streams: EVERY call orders the then-current stream behind the
+        answer and tells the allocator about that stream (events are cheap; a stream already ordered waits for nothing)."""
         if self._event is not None:
             cur = torch.cuda.current_stream(self._scores.device)
             cur.wait_event(self._event)
-            for t in (self._scores, self._indices, self._keep):  # allocated on the exchange stream, used on this one
+            for t in (self._scores, self._indices, self.gathered_status):  # allocated on another stream, used on this one
                 if t is not None:
                     t.record_stream(cur)
-            self._event = None
         return self._scores, self._indices
 
 
@@ -258,7 +260,13 @@ class EmbeddingBank:
             raise ValueError(f"queries must have shape [Q, {self.dim}], got {tuple(queries.shape)}")
         if queries.device != self.device:
             raise ValueError(f"queries are on {queries.device} but the bank is on {self.device}")
-        return queries.to(self.dtype).contiguous()
+        # float16 and float32 queries go to the library as they are: `isc_cosine_topk` rounds them to the bank dtype while
+        # it packs them (`q_dtype`; float32 -> fp16 round to nearest even, the arithmetic of `Tensor.to(float16)`), so the
+        # reference-shaped call `bank.search(predict_step(batch).get_flat_vectors())` -- float32 vectors, data.py:112-118 --
+        # runs no cast kernel.  Other floating types are converted here, directly to the bank dtype.
+        if queries.dtype not in (torch.float16, torch.float32):
+            queries = queries.to(self.dtype)
+        return queries if queries.stride(1) == 1 or queries.shape[0] == 0 else queries.contiguous()
 
     def _workspace(self, n_queries: int, k: int, lane: int = -1) -> Tensor:
         """The search workspace.  The C side runs a call as passes of at most `ISC_SEARCH_PASS_QUERIES` queries over
@@ -308,7 +316,8 @@ class EmbeddingBank:
         with torch.cuda.device(self.device):
             st = lib.isc_cosine_topk(
                 self._bank.data_ptr(), _lib.dtype_code(self.dtype), self.num_local_rows, self.dim, queries.data_ptr(),
-                nq, queries.stride(0), k, self.index_base, self._norm_bound.data_ptr(), scores.data_ptr(),
+                _lib.dtype_code(queries.dtype), nq, queries.stride(0), k, self.index_base, self._norm_bound.data_ptr(),
+                scores.data_ptr(),
                 indices.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(),
                 stream.cuda_stream if stream is not None else _lib.stream_handle(self.device),
             )
@@ -337,8 +346,8 @@ class EmbeddingBank:
         indices = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         with torch.cuda.device(self.device):
             st = lib.isc_cosine_topk_exhaustive(
-                self._bank.data_ptr(), code, self.num_local_rows, self.dim, q.data_ptr(), nq, q.stride(0), k,
-                self.index_base, scores.data_ptr(), indices.data_ptr(), ews.data_ptr(), ews.numel(),
+                self._bank.data_ptr(), code, self.num_local_rows, self.dim, q.data_ptr(), _lib.dtype_code(q.dtype), nq,
+                q.stride(0), k, self.index_base, scores.data_ptr(), indices.data_ptr(), ews.data_ptr(), ews.numel(),
                 _lib.stream_handle(self.device),
             )
         _lib.check(st, "isc_cosine_topk_exhaustive")
@@ -392,7 +401,12 @@ class EmbeddingBank:
         therefore has the short kernels at the end of search i (selection, exact re-score, the empty redo launches) and
         its exchange running beside the first kernels of search i + 1 -- at a 1.25 M-row shard 20 - 25 us of a 320 us
         search (`scripts/two_stream_probe.py`).  At most two searches of one bank should be unresolved at a time (a
-        third waits, on the device, for the first one)."""
+        third waits, on the device, for the first one).
+
+        Ownership until `handle.result()`: the search reads `queries` on a library-owned stream (float16 / float32
+        queries with unit inner stride are NOT copied), and writes `last_status` / `last_gathered_status` there -- so the
+        caller must not overwrite the query tensor in place, nor read those status tensors, on its own stream before it
+        has resolved the handle.  `search()` has no such window: everything it does is ordered on the caller's stream."""
         return self._search(queries, k, lanes=True)
 
     def _lane(self, cur: "torch.cuda.Stream", q: Tensor) -> tuple[int, "torch.cuda.Stream"]:
@@ -492,7 +506,7 @@ class EmbeddingBank:
         if not on_gpu:  # CPU tensors (the gloo rehearsal of the host logic): nothing to overlap
             out_s, out_i, gathered, gstatus = exchange()
             self.last_gathered_status = gstatus
-            return SearchHandle(out_s, out_i, None, gathered, gstatus)
+            return SearchHandle(out_s, out_i, None, gstatus)
         if self._xstream is None:
             self._xstream = torch.cuda.Stream(self.device)
         local_done = torch.cuda.Event()
@@ -505,7 +519,7 @@ class EmbeddingBank:
             done.record(self._xstream)
         slot.done = done
         self.last_gathered_status = gstatus  # valid once the handle has been resolved
-        return SearchHandle(out_s, out_i, done, gathered, gstatus)
+        return SearchHandle(out_s, out_i, done, gstatus)
 
     def _all_gather_bytes(self, xbuf: Tensor) -> Tensor:
         """`[G, nbytes]` uint8: every rank's exchange buffer (one all-gather; RCCL over xGMI on the GPUs)."""

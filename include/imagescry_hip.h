@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ISC_ABI_VERSION 3
+#define ISC_ABI_VERSION 4
 
 /* element types */
 #define ISC_U8 0
@@ -65,7 +65,9 @@ int isc_device_info(int* num_cus, int* lds_bytes_per_cu, char* arch_name, int ar
 
 /* Per-kernel device timing for the roofline line of bench.py.  While enabled, every launch of the kernels
  * below is bracketed by hipEvents recorded on the caller's stream; `isc_timing_read` synchronises those events,
- * returns the summed device time and the launch count since the last read, and clears them (host pointers). */
+ * returns the summed device time and the number of KERNEL launches since the last read (the unit a rocprofv3 kernel
+ * trace counts in: a convolution that runs as whole rounds + a half-tile remainder counts two), and clears them (host
+ * pointers). */
 #define ISC_KERNEL_DOTS_FILTER 0 /* k_dots_filter: the MFMA score + threshold-filter pass of isc_cosine_topk */
 #define ISC_KERNEL_CONV 1        /* k_conv_f32: the implicit-GEMM convolution of isc_conv2d_nhwc */
 #define ISC_KERNEL_GEMM_F16 2    /* k_gemm_f16: the fp16 GEMM of isc_gemm_f16 (transformer encoder) */
@@ -302,7 +304,11 @@ int isc_gram_rows(const float* xt, int F, int64_t n, float* gram, void* stream);
  * scores, queries of denormal or overflowing scale), the exhaustive float64 sweep.  No host round trip.
  *   bank         N rows of D values of `dtype` (ISC_F16 or ISC_F32) in the PACKED layout above (isc_bank_pack),
  *                16-byte aligned
- *   queries      row-major [Q, D] of the SAME dtype, leading dimension ldq (elements)
+ *   queries      row-major [Q, D] of `q_dtype` (ISC_F16 or ISC_F32, independent of the bank's), leading dimension ldq
+ *                (elements of q_dtype).  A query is ROUNDED TO THE BANK DTYPE first (float32 -> fp16 round to nearest
+ *                even, exactly `Tensor.to(float16)`; fp16 -> float32 is exact) while it is packed, so the reference-shaped
+ *                call `bank.search(predict_step(batch).get_flat_vectors())` (float32 vectors, reference
+ *                src/imagescry/data.py:112-118) against an fp16 bank needs no cast kernel
  *   k            1 <= k <= min(N, ISC_TOPK_MAX_K)
  *   index_base   added to every returned row index (global index of this shard's row 0)
  *   norm_bound   device float: upper bound of the stored rows' norms (isc_bank_pack); NULL = rows are unit length
@@ -319,16 +325,16 @@ int isc_gram_rows(const float* xt, int F, int64_t n, float* gram, void* stream);
 #define ISC_SEARCH_MAX_Q (1 << 24)
 #define ISC_SEARCH_PASS_QUERIES 1024 /* queries per pass; the workspace size depends on min(Q, this) rounded up to a query tile */
 int isc_cosine_topk_workspace_bytes(int dtype, int64_t N, int D, int Q, int k, size_t* bytes);
-int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, const void* queries, int Q, int64_t ldq, int k,
-                    int64_t index_base, const float* norm_bound, float* out_scores, int64_t* out_indices,
+int isc_cosine_topk(const void* bank, int dtype, int64_t N, int D, const void* queries, int q_dtype, int Q, int64_t ldq,
+                    int k, int64_t index_base, const float* norm_bound, float* out_scores, int64_t* out_indices,
                     int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same contract and the same limits, data-independent cost: every score of every query is evaluated in float64
  * (vector FMA, no matrix cores, about one bank stream per four queries).  The kernel isc_cosine_topk falls back to
  * per query; exported as the reference implementation of the search on the device. */
 int isc_cosine_topk_exhaustive_workspace_bytes(int dtype, int64_t N, int D, int Q, int k, size_t* bytes);
-int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N, int D, const void* queries, int Q, int64_t ldq,
-                               int k, int64_t index_base, float* out_scores, int64_t* out_indices,
+int isc_cosine_topk_exhaustive(const void* bank, int dtype, int64_t N, int D, const void* queries, int q_dtype, int Q,
+                               int64_t ldq, int k, int64_t index_base, float* out_scores, int64_t* out_indices,
                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* Merge G partial results (e.g. one per bank shard after the all-gather) into the final top-k by

@@ -40,11 +40,23 @@ def test_ctypes_table_matches_header() -> None:
     assert sorted(_lib.SIGNATURES) == declared_symbols()
 
 
+def test_search_entry_points_take_a_query_dtype() -> None:
+    """ABI 4: `isc_cosine_topk(bank, dtype, N, D, queries, q_dtype, Q, ldq, ...)` -- the queries
+    carry their own element type; header and ctypes table agree on where it sits."""
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    for name in ("isc_cosine_topk", "isc_cosine_topk_exhaustive"):
+        proto = re.search(rf"\bint {name}\s*\(([^;]*?)\);", text, flags=re.S).group(1)
+        params = [" ".join(a.split()) for a in proto.split(",")]
+        assert params[4] == "const void* queries" and params[5] == "int q_dtype" and params[6] == "int Q", params
+        assert len(_lib.SIGNATURES[name][1]) == len(params)
+        assert _lib.SIGNATURES[name][1][5] is ctypes.c_int and _lib.SIGNATURES[name][1][7] is ctypes.c_int64  # ldq
+
+
 def test_host_only_entry_points(library: ctypes.CDLL) -> None:
     """Functions that touch no device memory can run here: version, error strings, workspace sizing,
     argument validation."""
     lib = _lib.load()
-    assert lib.isc_abi_version() == _lib.ISC_ABI_VERSION == 3
+    assert lib.isc_abi_version() == _lib.ISC_ABI_VERSION == 4
     assert lib.isc_build_flags() == 0  # the production build: no ablation variants
     assert _lib.strerror(0) == "ok"
     assert "workspace" in _lib.strerror(_lib.ISC_ERR_WORKSPACE)

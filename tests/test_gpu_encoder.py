@@ -315,20 +315,30 @@ def test_embed_images_order_and_types(device: torch.device) -> None:
 
 
 def test_config0_encode_then_self_search(device: torch.device) -> None:
-    """BASELINE config 0 on the GPU path: encode random 224x224 images, search the embeddings against
-    themselves, every image finds itself first with score 1 +- 1e-5; a slice is compared with the oracle."""
+    """BASELINE config 0 at its own size on the GPU path: encode 256 random 224x224 images with the repo embedder, search
+    the 256 embeddings against themselves (brute-force cosine top-10), every image finds itself first with score
+    1 +- 1e-5; the whole search result equals the oracle's on the embeddings the GPU produced, and a 64-image slice of the
+    encode -- normalisation statistics are batch-wide, so a slice is its own batch -- is compared with the CPU oracle."""
     from imagescry_amd import EmbeddingBank, ImageBatch, ResNet50Embedder, resnet50
+    from oracle import search_oracle
 
     sd = resnet50.make_state_dict(seed=0)
     model = ResNet50Embedder(state_dict=sd).to(device)
-    images = cases.images_u8((64, 3, 224, 224))
-    out = model.predict_step(ImageBatch(indices=torch.arange(64), images=images).to(device))
+    n = 256
+    images = cases.images_u8((n, 3, 224, 224))
+    out = model.predict_step(ImageBatch(indices=torch.arange(n), images=images).to(device))
+    flat = out.get_flat_vectors()
+    assert flat.shape == (n, 768) and flat.dtype == torch.float32
     bank = EmbeddingBank.from_batches([out], dtype=torch.float32)
-    scores, indices = bank.search(out.get_flat_vectors(), 10)
-    assert indices[:, 0].cpu().tolist() == list(range(64))
-    assert torch.allclose(scores[:, 0].cpu(), torch.ones(64), atol=1e-5)
-    exp = encoder_oracle.predict_step_embeddings(images, sd)
-    np.testing.assert_allclose(out.embeddings.cpu().numpy(), exp.numpy(), rtol=0, atol=1e-5)
+    scores, indices = bank.search(flat, 10)
+    assert indices[:, 0].cpu().tolist() == list(range(n))
+    assert torch.allclose(scores[:, 0].cpu(), torch.ones(n), atol=1e-5)
+    exp_s, exp_i = search_oracle.cosine_topk(bank.bank.cpu(), flat.cpu(), 10)
+    np.testing.assert_array_equal(indices.cpu().numpy(), exp_i)
+    np.testing.assert_allclose(scores.cpu().numpy(), exp_s, rtol=0, atol=1e-6)
+    part = model.predict_step(ImageBatch(indices=torch.arange(64), images=images[:64]).to(device))
+    exp = encoder_oracle.predict_step_embeddings(images[:64], sd)
+    np.testing.assert_allclose(part.embeddings.cpu().numpy(), exp.numpy(), rtol=0, atol=1e-5)
 
 
 @pytest.mark.parametrize("name", ["resnet50", "efficientnet_s"])

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import search_oracle
+from props import assert_topk_properties
 
 pytestmark = pytest.mark.gpu
 
@@ -50,3 +51,46 @@ def test_pipeline_argument_checks(device):
     with pytest.raises(ValueError):
         EmbedSearchPipeline(embedding_model=model, bank=bank, k=0)
     assert EmbedSearchPipeline(embedding_model=model, bank=bank).run([]) == []
+
+
+def test_config5_at_its_own_size(device):
+    """BASELINE config 5 at ITS OWN size on one GPU: the ViT-B/16 embedder at depth 12 (fp16 operands), three DIFFERENT
+    batches of 512 images, pipelined on two HIP streams (`EmbedSearchPipeline(overlap=True)`) into a 50 000 000 x 768 fp16
+    bank (76.8 GB packed beside the 76.8 GB of row-major rows the proof reads: 154 of the 288 GB).  No CPU oracle finishes
+    this size, so every batch's answer is PROVEN on the device with the three size-independent properties -- sorted under
+    the total order, scores = float32(float64 cosine) of the returned rows, exactly k - 1 rows of the 50 M rank before the
+    k-th entry -- for the embeddings the GPU produced; the bank is `bench.make_shard`'s (one seed per 2^20-row block, the
+    bank `bench.py --workload pipeline` searches).  `last_status[:2] == [0, 0]`: no candidate buffer overflowed and no
+    query needed the second pass on this iid bank.  Falls back to the largest bank that fits when the device has less
+    memory free than the full size needs (the size used is asserted to be the configuration's on an MI355X)."""
+    import bench
+    from imagescry_amd import EmbeddingBank, EmbedSearchPipeline, ImageBatch, ViTB16Embedder
+
+    n, d, b, k = 50_000_000, 768, 512, 10
+    free = torch.cuda.mem_get_info(device)[0]
+    need = 2 * n * d * 2 + (24 << 30)  # rows + packed bank + encoder activations / workspaces / proof blocks
+    if free < need:  # not an MI355X-sized device: the largest multiple of 2^20 rows that fits
+        n = max(1 << 20, int((free - (24 << 30)) // (2 * d * 2)) >> 20 << 20)
+    rows = bench.make_shard(0, n, d, device)
+    bank = EmbeddingBank(rows, dtype=torch.float16, normalize=False)
+    model = ViTB16Embedder(seed=0).to(device)
+    assert model.config.depth == 12 and model.embedding_dim == d
+    g = torch.Generator().manual_seed(4321)
+    batches = [ImageBatch(indices=torch.arange(b) + b * j,
+                          images=torch.randint(0, 256, (b, 3, 224, 224), dtype=torch.uint8, generator=g)) for j in range(3)]
+    pipe = EmbedSearchPipeline(embedding_model=model, bank=bank, k=k, overlap=True)
+    results = pipe.run(batches)
+    assert len(results) == 3
+    assert bank.last_status.cpu().tolist()[:2] == [0, 0]
+    assert int(pipe.exact_pass_queries.item()) == 0
+    seen = []
+    for batch, res in zip(batches, results):
+        assert torch.equal(res.indices.cpu(), batch.indices)
+        assert res.scores.shape == (b, k) and res.neighbours.shape == (b, k)
+        # the queries the search saw: the embedder's float32 vectors rounded to the bank dtype (isc_cosine_topk's q_dtype)
+        q = model.predict_step(batch.to(device)).get_flat_vectors().to(torch.float16)
+        assert_topk_properties(rows, q, res.scores, res.neighbours, k, block=1 << 18)
+        seen.append(res.neighbours[:, 0].clone())
+    assert not torch.equal(seen[0], seen[1])  # different images, different neighbours
+    if torch.cuda.get_device_properties(device).total_memory >= 250 << 30:
+        assert n == 50_000_000

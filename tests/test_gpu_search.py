@@ -18,6 +18,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
 import cases  # noqa: E402
 
 from oracle import search_oracle  # noqa: E402
+from props import assert_topk_properties as _assert_topk_properties  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -128,7 +129,8 @@ def test_signed_zero_scores_are_one_score(device: torch.device) -> None:
 
 
 def test_bank_normalisation_and_fp32_queries(device: torch.device) -> None:
-    """`normalize=True` applies the F.normalize formula before the cast; float32 queries are cast to the bank dtype."""
+    """`normalize=True` applies the F.normalize formula before the cast; float32 queries are rounded to the bank dtype
+    (inside `isc_cosine_topk`, ABI 4)."""
     g = cases.gen(5)
     raw = torch.randn(3000, 192, generator=g) * 4.0
     queries = torch.randn(6, 192, generator=g)
@@ -141,6 +143,57 @@ def test_bank_normalisation_and_fp32_queries(device: torch.device) -> None:
     exp_s, exp_i = search_oracle.cosine_topk(stored, queries.half(), 10)
     scores, indices = eb.search(queries.to(device), 10)
     _check(scores, indices, exp_s, exp_i)
+
+
+@pytest.mark.parametrize("bank_dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("n,d,nq", [(3000, 192, 6), (70_000, 768, 200), (20_000, 100, 1030)])
+def test_query_dtype_is_independent_of_the_bank_dtype(bank_dtype: torch.dtype, n: int, d: int, nq: int,
+                                                      device: torch.device) -> None:
+    """ABI 4: `isc_cosine_topk` takes the queries in their own element type (`q_dtype`) and rounds them to the bank dtype
+    while it packs them -- float32 -> fp16 by round to nearest even, the arithmetic of `Tensor.to(float16)`; fp16 -> float32
+    exactly.  So float32 queries against an fp16 bank (the reference-shaped call: `get_flat_vectors()` is float32,
+    data.py:112-118) give BIT-IDENTICAL (scores, indices) to cast-then-search, with no cast kernel in front; likewise fp16
+    queries against a float32 bank; the exhaustive kernel rounds the same way; and the result equals the oracle's for the
+    cast queries.  Queries include values that round across an fp16 binade, fp16 denormals, overflow to inf and a
+    non-unit leading dimension."""
+    from imagescry_amd import EmbeddingBank, _lib
+
+    g = cases.gen(n + nq)
+    bank = search_oracle.l2_normalize_rows(torch.randn(n, d, generator=g)).to(bank_dtype)
+    eb = EmbeddingBank(bank.to(device), dtype=bank_dtype, normalize=False)
+    k = 10
+    for q_dtype in (torch.float32, torch.float16):
+        wide = torch.randn(nq, d + 8, generator=g)
+        wide[0, :4] = torch.tensor([2049.0, 1.0 + 2.0 ** -11, 3.0e-8, 6.0e-6])  # ties-to-even, fp16 denormals
+        if nq > 3:
+            wide[3, 0] = 1.0e5  # float32 -> fp16: inf
+        wide = wide.to(q_dtype).to(device)
+        queries = wide[:, :d]  # ldq = d + 8: the library reads the rows in place
+        assert queries.stride(0) == d + 8
+        cast = queries.to(bank_dtype).contiguous()  # what the host used to do in front of the call (an ATen cast kernel)
+        got_s, got_i = eb.search(queries, k)
+        ref_s, ref_i = eb.search(cast, k)
+        assert torch.equal(got_i, ref_i)
+        assert torch.equal(got_s.view(torch.int32), ref_s.view(torch.int32))  # bit for bit, NaN rows included
+        if n <= 20_000:
+            ex_s, ex_i = eb.search_exhaustive(queries, k)
+            ex2_s, ex2_i = eb.search_exhaustive(cast, k)
+            assert torch.equal(ex_i, ex2_i) and torch.equal(ex_s.view(torch.int32), ex2_s.view(torch.int32))
+        exp_s, exp_i = search_oracle.cosine_topk(bank, cast.cpu(), k)
+        _check(got_s, got_i, exp_s, exp_i)
+    # the C entry point itself: a q_dtype that is no float type is refused before anything is launched
+    need = _lib.c_size_t()
+    code = _lib.dtype_code(bank_dtype)
+    lib = _lib.load()
+    _lib.check(lib.isc_cosine_topk_workspace_bytes(code, n, d, 2, k, need), "ws")
+    ws = torch.empty(need.value, dtype=torch.uint8, device=device)
+    s = torch.empty((2, k), dtype=torch.float32, device=device)
+    i = torch.empty((2, k), dtype=torch.int64, device=device)
+    st4 = torch.empty(4, dtype=torch.int32, device=device)
+    bad = lib.isc_cosine_topk(eb._bank.data_ptr(), code, n, d, cast.data_ptr(), _lib.ISC_U8, 2, d, k, 0, None,
+                              s.data_ptr(), i.data_ptr(), st4.data_ptr(), ws.data_ptr(), ws.numel(),
+                              _lib.stream_handle(device))
+    assert bad == _lib.ISC_ERR_INVALID_ARG
 
 
 def test_index_base_and_merge_equal_unsharded(device: torch.device) -> None:
@@ -178,7 +231,7 @@ def test_exhaustive_kernel_matches_oracle(device: torch.device) -> None:
         s = torch.empty((11, k), dtype=torch.float32, device=device)
         i = torch.empty((11, k), dtype=torch.int64, device=device)
         st = lib.isc_cosine_topk_exhaustive(
-            eb._bank.data_ptr(), code, 5000, 160, q.data_ptr(), 11, 160, k, 1000, s.data_ptr(), i.data_ptr(),
+            eb._bank.data_ptr(), code, 5000, 160, q.data_ptr(), code, 11, 160, k, 1000, s.data_ptr(), i.data_ptr(),
             ws.data_ptr(), ws.numel(), _lib.stream_handle(device),
         )
         _lib.check(st, "isc_cosine_topk_exhaustive")
@@ -389,30 +442,6 @@ def test_argument_errors(device: torch.device) -> None:
     wide = EmbeddingBank(torch.randn(40, _lib.ISC_SEARCH_MAX_D + 8, device=device), dtype=torch.float16)
     with pytest.raises(ValueError):  # rejected up front by the fast path, not by its fallback in mid-call
         wide.search(torch.randn(2, _lib.ISC_SEARCH_MAX_D + 8, device=device), 5)
-
-
-def _assert_topk_properties(bank_rows: torch.Tensor, queries: torch.Tensor, scores: torch.Tensor, indices: torch.Tensor,
-                            k: int, block: int = 65536) -> None:
-    """Size-independent proof that (scores, indices) is THE cosine top-k of `queries` over `bank_rows` (row-major, on the
-    GPU): sorted under the total order; the scores are the exact cosines of the returned rows; no row outside the set
-    beats or ties-with-lower-index the k-th entry.  torch float64 matmuls on the device, test-side only."""
-    n, d = bank_rows.shape
-    q = queries.shape[0]
-    s, i = scores.double(), indices
-    assert bool(((s[:, :-1] > s[:, 1:]) | ((s[:, :-1] == s[:, 1:]) & (i[:, :-1] < i[:, 1:]))).all())
-    q64 = queries.double()
-    denom = q64.norm(dim=1).clamp_min(1e-12)
-    rows = bank_rows[indices.reshape(-1)].double().reshape(q, k, d)
-    exact = (torch.einsum("qkd,qd->qk", rows, q64) / denom[:, None]).float()
-    assert torch.allclose(scores, exact, rtol=0, atol=1e-7)
-    kth = scores[:, -1].double()
-    kth_idx = indices[:, -1]
-    better = torch.zeros(q, dtype=torch.int64, device=scores.device)
-    for r0 in range(0, n, block):
-        blk = (q64 @ bank_rows[r0 : r0 + block].double().T / denom[:, None]).float().double()
-        ridx = torch.arange(r0, r0 + blk.shape[1], device=scores.device)[None, :]
-        better += ((blk > kth[:, None]) | ((blk == kth[:, None]) & (ridx < kth_idx[:, None]))).sum(dim=1)
-    assert bool((better == k - 1).all())
 
 
 def test_full_size_properties_1m(device: torch.device) -> None:
