@@ -84,6 +84,11 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
         [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
          c_void_p, c_void_p],
     ),
+    "isc_conv2d_nhwc_dual": (
+        c_int,
+        [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+         c_int, c_void_p, c_void_p],
+    ),
     "isc_conv2d_nhwc_gated": (
         c_int,
         [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,

@@ -175,7 +175,7 @@ Plan make_plan(int64_t n, int q, int k) {
         // the sample's weak threshold -- a wave's ballot over 128 rows x 16 queries trips with probability
         // 1 - exp(-2048 kp / rows seen), 39 % after 65 536 rows, and every trip is a scan of the block.  A short
         // intermediate level buys a threshold that trips 3 % for the price of one k_select: 10 M rows at Q = 256
-        // 4.17 -> 4.00 ms (scripts/ab_first_ratio.sh).  With four query tiles (Q = 1024) the same level costs more than it
+        // 4.17 -> 4.00 ms (scripts/ab.sh, ab_first_ratio).  With four query tiles (Q = 1024) the same level costs more than it
         // saves (13.34 -> 13.67 ms at ratio 8, no change at 16), so it is not used there.
         if (p.tnq == 256 && p.qtiles == 1 && p.nlevels == 1 && ratio > first_ratio()) ratio = first_ratio();
         if (ratio < 3) ratio = 3;
@@ -375,7 +375,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 constexpr int A_TILE_BYTES = TM * 128;  // 32 KiB: one K step of one bank tile
 
 // Tuning constants of the 256-query loop.  They are macros so that `python -m imagescry_amd.build --variant=<name> -D...`
-// can build A/B libraries (scripts/ab_asym.sh, scripts/ab_hm.sh); the values below are what the measurements kept.
+// can build A/B libraries (scripts/ab.sh: ab_asym, ab_hm); the values below are what the measurements kept.
 #ifndef ISC_ASYM_MBLO
 #define ISC_ASYM_MBLO 6  // row blocks of a wm = 0 wave (of 16 per tile) in launches with several query tiles
 #endif
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     // (2 890 cycles; without the static priority the roles swap, the picture stays).  So the favoured waves own MBHI of the
     // tile's 16 row blocks and the others MBLO.  Sample launches (one tile per workgroup) and the 64-query shape stay
     // symmetric.
-    // Ablations of the query operand (what do its LDS bytes cost?  DESIGN 8, scripts/ab_noq.sh): 41 = neither staged nor
+    // Ablations of the query operand (what do its LDS bytes cost?  LABLOG.md, scripts/ab.sh: ab_noq): 41 = neither staged nor
     // read (garbage fragments), 43 = staged (LDS-DMA writes) but never read.
     constexpr bool NOBREAD = (MODE == 41 || MODE == 43) && TNQ == 256;
     constexpr bool NOBDMA = MODE == 41 && TNQ == 256;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     // the first half's query fragments stand between the barrier and the first MFMA of a step (the second half's are
     // fetched under the first units), and the bank fragments run three units ahead through four registers.
     // It is the form of every launch with several query tiles (MODE 12); MODE 48 (ablation builds) = the row-block-major
-    // form it replaced (+1.6 %, scripts/ab_hm.sh), which the stamped build (22) and the operand ablations (41, 43) still run.
+    // form it replaced (+1.6 %, scripts/ab.sh: ab_hm), which the stamped build (22) and the operand ablations (41, 43) still run.
     constexpr bool HM = MODE == 12 && TNQ == 256 && !SAMPLE;
     constexpr bool NOSPLIT_FORM = MODE == 12 || MODE == 22 || MODE == 41 || MODE == 43 || MODE == 48;
     constexpr int ASYM_LO = NOSPLIT_FORM ? ISC_ASYM_MBLO : MODE == 0 ? ISC_ASYM_SPLIT_MBLO : 8;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     // Static priority for the second-dispatched half of the workgroup (waves 4 - 7, the wm = 1 partners of every SIMD in
     // the 256-query shape): that half loses the SIMD's issue arbitration to the older half on every segment
     // (MI355X_MICROARCH.md, "Two waves per SIMD" item 4); one s_setprio before the loop, no flips inside.  +1.0 % at
-    // Q = 1024 (scripts/ab_headline.sh, three interleaved rounds: 13.71 -> 13.57 ms); per-cluster flips lost 5 % in round 1.
+    // Q = 1024 (scripts/ab.sh: ab_headline, three interleaved rounds: 13.71 -> 13.57 ms); per-cluster flips lost 5 % in round 1.
     // The condition must be provably wave-uniform: s_setprio is a scalar instruction that ignores EXEC.
     // Not with SPLIT (MODE 0: only the older half issues the LDS-DMA there, and prioritising the other half on top of
     // that cost 4 %).

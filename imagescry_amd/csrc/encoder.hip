@@ -35,6 +35,11 @@ struct ConvParams {
     const float* res;
     const float* sub;    // optional per-input-channel vector subtracted from x before the product (PCA centring)
     const float* scale;  // optional [B, Cin] factor applied to x before the product (squeeze-excitation gate)
+    // optional SECOND input of a 1 x 1 convolution, K-concatenated: out = act(w[:, :Cin] . x + w[:, Cin:] . x2 + bias):
+    // x2 float [B, H2, W2, Cin2], read at (ho * stride2, wo * stride2) -- a ResNet block's 1 x 1 downsample branch folded
+    // into its conv3, so that the branch's output is never written and read back as a residual.  K steps >= x2_step0.
+    const float* x2;
+    int x2_step0, H2, W2, Cin2, stride2;
     float* out;
     int B, H, W, Cin, Cout, R, S, stride, pad, Ho, Wo;
     int M;          // B * Ho * Wo output pixels
@@ -99,8 +104,11 @@ __device__ __forceinline__ void conv_dma16(const void* gsrc, unsigned char* lds_
 // taps that fall outside the image read a page of zeros) instead of global loads into registers + ds_write_b128: no
 // staging registers, no LDS store instructions; the fragment reads then have to be inline asm (a C++ LDS load makes hipcc
 // drain the DMA in flight before it).  Used whenever no per-element transform of x is asked for (`sub`, `scale`).
-template <int TCO, int TPIX, bool TAP4, bool DMA>
+// DUAL = the instantiation that knows the K-concatenated second input (ConvParams::x2); a kernel of its own so that the
+// plain ones keep their register allocation (with the branch in every instantiation the 64 x 256 tile spilled 35 registers).
+template <int TCO, int TPIX, bool TAP4, bool DMA, bool DUAL = false>
 __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int ntiles) {
+    static_assert(!DUAL || (DMA && !TAP4), "the second input exists in the LDS-DMA form without packed-K only");
     constexpr int WCO = TCO >= 64 ? TCO / 64 : 1;  // waves along the output channels
     constexpr int MI = TCO / WCO / 16;             // 16-channel blocks per wave: 4, or 2 for the 32-channel tile
     constexpr int NA = TCO * 8 / 256;      // 16-byte staging slots per thread, weight tile
@@ -284,6 +292,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int nti
                 const int wi = (int)(short)(b_hw0[i] & 0xffff) + s;
                 const bool ok = tap_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 const float* src = ok ? p.x + (size_t)(b_base[i] + (hi * p.W + wi) * p.Cin + c4 * 4) : g_zero_line + lchunk * 4;
+                conv_dma16(src, b + 4096 * i);
+            }
+        } else if (DUAL && ks >= p.x2_step0) {
+            // the K steps of the second input (the main convolution is 1 x 1 / stride 1 / pad 0, so b_hw0 holds the output
+            // pixel itself): 32 channels of x2 at (ho * stride2, wo * stride2); the weight rows are [Cin | Cin2]
+            const int c0 = (ks - p.x2_step0) * 32;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) conv_dma16(p.w + (size_t)(a_off[i] + ks * 32), a + 4096 * i);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int ho = b_hw0[i] >> 16;
+                const int wo = (int)(short)(b_hw0[i] & 0xffff);
+                const float* src = ho >= 0 ? p.x2 + ((size_t)((b_img[i] * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) *
+                                                         (size_t)p.Cin2 + (size_t)(c0 + lchunk * 4))
+                                           : g_zero_line + lchunk * 4;  // rows past M
                 conv_dma16(src, b + 4096 * i);
             }
         } else {
@@ -1014,9 +1037,14 @@ static bool conv_no_split() {
 static constexpr bool conv_no_split() { return false; }
 #endif
 
+struct ConvSecondInput {  // see ConvParams::x2
+    const float* x2 = nullptr;
+    int H2 = 0, W2 = 0, Cin2 = 0, stride2 = 1;
+};
+
 static int conv_launch(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S, int stride,
                        int pad, const float* bias, const float* residual, const float* sub, const float* scale, int act,
-                       float* out, void* stream) {
+                       float* out, void* stream, const ConvSecondInput second = ConvSecondInput{}) {
     ISC_REQUIRE(x && w && out);
     ISC_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0);
     const int res_after_act = (act & ISC_ACT_RESIDUAL_AFTER) ? 1 : 0;
@@ -1030,7 +1058,17 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     const int Wo = (W + 2 * pad - S) / stride + 1;
     ISC_REQUIRE(Ho > 0 && Wo > 0);
     const int64_t M = (int64_t)B * Ho * Wo;
-    const int ksteps = tap4 ? isc_ceil_div(R * S * Cin, 32) : R * S * (Cin / 32);
+    int ksteps = tap4 ? isc_ceil_div(R * S * Cin, 32) : R * S * (Cin / 32);
+    const int x2_step0 = ksteps;
+    if (second.x2) {  // K-concatenated second 1 x 1 input: the LDS-DMA form of a plain 1 x 1 / 1 / 0 convolution only
+        if (tap4 || sub || scale || R != 1 || S != 1 || stride != 1 || pad != 0) return ISC_ERR_UNSUPPORTED;
+        ISC_REQUIRE(second.H2 > 0 && second.W2 > 0 && second.Cin2 > 0 && second.stride2 > 0);
+        if (second.Cin2 % 32 != 0) return ISC_ERR_UNSUPPORTED;
+        ISC_REQUIRE((second.H2 - 1) / second.stride2 + 1 == H && (second.W2 - 1) / second.stride2 + 1 == W);
+        if ((int64_t)B * second.H2 * second.W2 >= (1ll << 31)) return ISC_ERR_UNSUPPORTED;
+        if (!isc_aligned(second.x2, 16)) return ISC_ERR_ALIGNMENT;
+        ksteps += second.Cin2 / 32;
+    }
     const int64_t K = (int64_t)ksteps * 32;
     if ((int64_t)B * H * W * Cin >= (1ll << 31) || M * Cout >= (1ll << 31) || (int64_t)Cout * K >= (1ll << 31))
         return ISC_ERR_UNSUPPORTED;  // 32-bit element offsets inside the kernel
@@ -1039,6 +1077,7 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
         return ISC_ERR_ALIGNMENT;
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.res = residual; p.sub = sub; p.scale = scale; p.out = out;
+    p.x2 = second.x2; p.x2_step0 = x2_step0; p.H2 = second.H2; p.W2 = second.W2; p.Cin2 = second.Cin2; p.stride2 = second.stride2;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K; p.cin_steps = tap4 ? 1 : Cin / 32; p.cin4 = Cin / 4; p.ksteps = ksteps; p.act = act; p.res_after_act = res_after_act; p.tile_base = 0; p.tile_split = 1;
     conv_fastdiv((unsigned)(Ho * Wo), &p.div_hw_mul, &p.div_hw_sh);
@@ -1058,6 +1097,12 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     const int64_t resident = 2 * (int64_t)conv_cu_count();
     const dim3 grid((unsigned)(dma && !conv_one_tile_per_wg() && blocks > resident ? resident : blocks)), block(256);
     isc_timing_begin(ISC_KERNEL_CONV, s);
+    if (second.x2) {  // the K-concatenated form: its own instantiations, one launch
+        if (narrow) hipLaunchKernelGGL((k_conv_f32<64, 256, false, true, true>), grid, block, 0, s, p, ntiles);
+        else hipLaunchKernelGGL((k_conv_f32<128, 128, false, true, true>), grid, block, 0, s, p, ntiles);
+        isc_timing_end(ISC_KERNEL_CONV, s);
+        return isc_launch_status();
+    }
     // A tile count that leaves a thin last round on the resident workgroups (ResNet-50 layer3 / layer4: 1 568 and 784
     // tiles on 512): whole rounds as one perfectly balanced launch, the remainder as HALF tiles (128 x 64, 64 x 128) in a
     // second one -- its round then costs half a tile time, or spreads over twice the CUs, instead of a whole one.  Worth a
@@ -1108,6 +1153,15 @@ extern "C" int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, con
                                int stride, int pad, const float* bias, const float* residual, int act, float* out,
                                void* stream) {
     return conv_launch(x, B, H, W, Cin, w, Cout, R, S, stride, pad, bias, residual, nullptr, nullptr, act, out, stream);
+}
+
+extern "C" int isc_conv2d_nhwc_dual(const float* x, int B, int H, int W, int Cin, const float* x2, int H2, int W2, int Cin2,
+                                    int stride2, const float* w, int Cout, const float* bias, const float* residual,
+                                    int act, float* out, void* stream) {
+    ISC_REQUIRE(x2);
+    ConvSecondInput second;
+    second.x2 = x2; second.H2 = H2; second.W2 = W2; second.Cin2 = Cin2; second.stride2 = stride2;
+    return conv_launch(x, B, H, W, Cin, w, Cout, 1, 1, 1, 0, bias, residual, nullptr, nullptr, act, out, stream, second);
 }
 
 extern "C" int isc_conv2d_nhwc_gated(const float* x, int B, int H, int W, int Cin, const float* gate, const float* w,

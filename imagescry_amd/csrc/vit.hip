@@ -569,15 +569,26 @@ void launch_layernorm(int nv, dim3 grid, hipStream_t s, const float* x, long lon
 //                                       to keys is free as long as both operands agree: slot (g, j) <-> key
 //                                       32 ks + 4 g + j (j < 4) or 32 ks + 16 + 4 g + (j - 4).  With that mapping the
 //                                       P^T operand is exactly what the lane already holds after the softmax, so the
-//                                       probabilities never leave registers; V^T is read as two 8-byte LDS loads.
+//                                       probabilities never leave registers; V^T is stored with its columns in that
+//                                       order, one 16-byte LDS load per fragment.
 constexpr int ATT_TMAX = 224;
 constexpr int ATT_KSTRIDE = 72;   // halves per key row (64 + 8 pad)
 constexpr int ATT_VSTRIDE = 232;  // halves per value^T row (224 + 8 pad)
 constexpr int ATT_THREADS = 512;
 
-template <bool PACKED>
+// NKB = key blocks of 16 the kernel computes (T <= 16 NKB).  TAIL: T > 16 (NKB - 1), so only the LAST key block holds
+// keys past T and only it is masked -- the shape of every ViT launch (T = 197: NKB = 13, the fourteenth block, which is
+// all padding, is never computed); the generic form (NKB = 14, TAIL = false) masks every element and serves any T.
+//
+// Softmax arithmetic (round 4; the kernel is bound by its vector ALU work): the exponent is ONE fused
+// multiply-add on the score -- exp(s - m) = exp2(s * log2(e) - m * log2(e)) with the second product hoisted out of the
+// loop -- feeding v_exp_f32 directly, instead of a subtraction, a multiplication and the exponential; the masks shrink
+// from two instructions per score to two per score of ONE block.  Per 16-query block: ~230 vector instructions instead
+// of ~390 (28 K-fragment reads, 26 + 28 MFMAs).
+template <bool PACKED, int NKB, bool TAIL>
 __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* __restrict__ qkv, int T, int heads,
                                                                 _Float16* __restrict__ out) {
+    static_assert(NKB >= 1 && NKB <= ATT_TMAX / 16, "key blocks");
     __shared__ __attribute__((aligned(16))) _Float16 Ks[ATT_TMAX * ATT_KSTRIDE];
     __shared__ __attribute__((aligned(16))) _Float16 Vt[64 * ATT_VSTRIDE];
     const int b = blockIdx.x / heads;
@@ -593,7 +604,8 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
         return base + (size_t)t * row_stride + part * D + c * 8;
     };
 
-    for (int i = tid; i < ATT_TMAX * 8; i += ATT_THREADS) {
+    constexpr int TROWS = NKB * 16 < ATT_TMAX ? (NKB + (NKB & 1)) * 16 : ATT_TMAX;  // key rows staged (whole MFMA k-steps of 32)
+    for (int i = tid; i < TROWS * 8; i += ATT_THREADS) {
         const int t = i >> 3, c = i & 7;
         half8 kv = half8{0, 0, 0, 0, 0, 0, 0, 0};
         half8 vv = kv;
@@ -602,8 +614,13 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
             vv = *reinterpret_cast<const half8*>(qkv_at(t, 2, c));
         }
         *reinterpret_cast<half8*>(&Ks[t * ATT_KSTRIDE + c * 8]) = kv;
+        // value^T columns are stored in the order the P^T operand holds its keys: inside every group of 32 keys, key
+        // 4 g + j (j < 4) sits at column 8 g + j and key 16 + 4 g + j at column 8 g + 4 + j, so the eight values a lane
+        // feeds to one MFMA are 16 contiguous bytes (one ds_read_b128 instead of a ds_read2_b64 at twice the LDS cycles)
+        const int u = t & 31;
+        const int tp = (t & ~31) + ((u & 12) << 1) + ((u & 16) >> 2) + (u & 3);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * ATT_VSTRIDE + t] = vv[j];
+        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * ATT_VSTRIDE + tp] = vv[j];
     }
     __syncthreads();
 
@@ -612,6 +629,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
     const int qi = lane & 15;
     const int g = lane >> 4;
     const int nqb = (T + 15) >> 4;
+    constexpr float LOG2E = 1.4426950408889634f;
     for (int qb = wave; qb < nqb; qb += ATT_THREADS / 64) {
         const int tq = qb * 16 + qi;
         half8 qf[2];
@@ -621,32 +639,64 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
 #pragma unroll
             for (int j = 0; j < 8; ++j) qf[kk][j] = qf[kk][j] * (_Float16)0.125f;  // 1/sqrt(64): exact scaling
         }
-        f32x4 s[14];
+        f32x4 s[NKB];
         float mx = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < 14; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
             f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const half8 kf = *reinterpret_cast<const half8*>(&Ks[(kb * 16 + qi) * ATT_KSTRIDE + (kk * 4 + g) * 8]);
                 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], a, 0, 0, 0);
             }
+            if (!TAIL || kb == NKB - 1) {  // (compile-time) the block(s) that can hold keys past T
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (kb * 16 + g * 4 + r >= T) a[r] = -INFINITY;
-                mx = fmaxf(mx, a[r]);
+                for (int r = 0; r < 4; ++r)
+                    if (kb * 16 + g * 4 + r >= T) a[r] = -INFINITY;
             }
             s[kb] = a;
             __builtin_amdgcn_sched_barrier(0);  // keep the fragment loads of later key blocks from piling up in VGPRs
         }
+        // The row maximum, v_max3_f32 by hand: through fmaxf the compiler first canonicalises every matrix-core result (one
+        // v_max_f32 x, x each -- 52 more instructions per query block than the 26 maxima themselves).  hipcc pads no
+        // hazards for an asm statement (cdna_hip_programming.md 5.7), and a vector instruction that reads a register a
+        // matrix-core instruction has just written needs its wait states: so the maxima run in ONE block behind the whole
+        // score loop, fenced from it by a scheduling barrier, and the block opens with those wait states itself (12 >= the 11
+        // an 8-pass MFMA result needs; the last MFMA's result is read by the mask code in between at the earliest).
+        __builtin_amdgcn_sched_barrier(0);
+        // six score blocks (twelve v_max3_f32) per statement: 25 register operands, under the limit of 30
+#define ISC_ATT_MAX6(k_, PRE_)                                                                                         \
+    asm volatile(PRE_ "v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\t"         \
+                 "v_max3_f32 %0, %0, %7, %8\n\tv_max3_f32 %0, %0, %9, %10\n\tv_max3_f32 %0, %0, %11, %12\n\t"           \
+                 "v_max3_f32 %0, %0, %13, %14\n\tv_max3_f32 %0, %0, %15, %16\n\tv_max3_f32 %0, %0, %17, %18\n\t"        \
+                 "v_max3_f32 %0, %0, %19, %20\n\tv_max3_f32 %0, %0, %21, %22\n\tv_max3_f32 %0, %0, %23, %24"             \
+                 : "+v"(mx)                                                                                            \
+                 : "v"(s[k_][0]), "v"(s[k_][1]), "v"(s[k_][2]), "v"(s[k_][3]), "v"(s[k_ + 1][0]), "v"(s[k_ + 1][1]),   \
+                   "v"(s[k_ + 1][2]), "v"(s[k_ + 1][3]), "v"(s[k_ + 2][0]), "v"(s[k_ + 2][1]), "v"(s[k_ + 2][2]),      \
+                   "v"(s[k_ + 2][3]), "v"(s[k_ + 3][0]), "v"(s[k_ + 3][1]), "v"(s[k_ + 3][2]), "v"(s[k_ + 3][3]),      \
+                   "v"(s[k_ + 4][0]), "v"(s[k_ + 4][1]), "v"(s[k_ + 4][2]), "v"(s[k_ + 4][3]), "v"(s[k_ + 5][0]),      \
+                   "v"(s[k_ + 5][1]), "v"(s[k_ + 5][2]), "v"(s[k_ + 5][3]))
+#define ISC_ATT_MAX1(k_)                                                                  \
+    asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4"                  \
+                 : "+v"(mx)                                                               \
+                 : "v"(s[k_][0]), "v"(s[k_][1]), "v"(s[k_][2]), "v"(s[k_][3]))
+        static_assert(NKB == 13 || NKB == 14, "the maxima are written out for thirteen or fourteen key blocks");
+        ISC_ATT_MAX6(0, "s_nop 7\n\ts_nop 3\n\t");  // the wait states of the matrix-core results, inside the statement
+        ISC_ATT_MAX6(6, "");
+        ISC_ATT_MAX1(12);
+        if constexpr (NKB == 14) ISC_ATT_MAX1(NKB - 1);
+#undef ISC_ATT_MAX6
+#undef ISC_ATT_MAX1
+        __builtin_amdgcn_sched_barrier(0);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mxl = -mx * LOG2E;  // T >= 1: every query has a finite maximum
         float sum = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 14; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[kb][r] - mx);
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, mxl));  // masked keys: exp2(-inf) = 0
                 s[kb][r] = e;
                 sum += e;
             }
@@ -658,19 +708,16 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
 #pragma unroll
         for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 7; ++ks) {
+        for (int ks = 0; ks < (NKB + 1) / 2; ++ks) {
             half8 pf;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 pf[r] = (_Float16)s[2 * ks][r];
-                pf[4 + r] = (_Float16)s[2 * ks + 1][r];
+                pf[4 + r] = 2 * ks + 1 < NKB ? (_Float16)s[2 * ks + 1 < NKB ? 2 * ks + 1 : 0][r] : (_Float16)0.f;
             }
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const _Float16* vrow = &Vt[(db * 16 + qi) * ATT_VSTRIDE + ks * 32 + g * 4];
-                const half4 lo = *reinterpret_cast<const half4*>(vrow);
-                const half4 hi = *reinterpret_cast<const half4*>(vrow + 16);
-                const half8 vf = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const half8 vf = *reinterpret_cast<const half8*>(&Vt[(db * 16 + qi) * ATT_VSTRIDE + ks * 32 + g * 8]);
                 o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[db], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -857,12 +904,23 @@ extern "C" int isc_attention_f16(const void* qkv, int B, int T, int heads, int h
     if (head_dim != 64 || T > ATT_TMAX) return ISC_ERR_UNSUPPORTED;
     if (!isc_aligned(qkv, 16) || !isc_aligned(out, 16)) return ISC_ERR_ALIGNMENT;
     if ((long long)B * heads > 0x7fffffffLL) return ISC_ERR_UNSUPPORTED;
-    if (packed)
-        hipLaunchKernelGGL(k_attention_f16<true>, dim3((unsigned)(B * heads)), dim3(ATT_THREADS), 0, isc_stream(stream),
-                           reinterpret_cast<const _Float16*>(qkv), T, heads, reinterpret_cast<_Float16*>(out));
-    else
-        hipLaunchKernelGGL(k_attention_f16<false>, dim3((unsigned)(B * heads)), dim3(ATT_THREADS), 0, isc_stream(stream),
-                           reinterpret_cast<const _Float16*>(qkv), T, heads, reinterpret_cast<_Float16*>(out));
+#define ISC_ATT_LAUNCH(PK_, NKB_, TAIL_)                                                                              \
+    hipLaunchKernelGGL((k_attention_f16<PK_, NKB_, TAIL_>), dim3((unsigned)(B * heads)), dim3(ATT_THREADS), 0,          \
+                       isc_stream(stream), reinterpret_cast<const _Float16*>(qkv), T, heads,                            \
+                       reinterpret_cast<_Float16*>(out))
+    // 192 < T <= 208 (ViT-B/16: 197 tokens): thirteen key blocks, only the last one masked; 208 < T: fourteen, likewise;
+    // anything shorter: the generic form (fourteen blocks, every element masked)
+    if (T > 208) {
+        if (packed) ISC_ATT_LAUNCH(true, 14, true);
+        else ISC_ATT_LAUNCH(false, 14, true);
+    } else if (T > 192) {
+        if (packed) ISC_ATT_LAUNCH(true, 13, true);
+        else ISC_ATT_LAUNCH(false, 13, true);
+    } else {
+        if (packed) ISC_ATT_LAUNCH(true, 14, false);
+        else ISC_ATT_LAUNCH(false, 14, false);
+    }
+#undef ISC_ATT_LAUNCH
     return isc_launch_status();
 }
 

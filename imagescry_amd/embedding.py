@@ -184,6 +184,21 @@ def _conv(x: Tensor, conv: resnet50.FoldedConv, act: int, residual: Tensor | Non
     return out
 
 
+def _conv_dual(x: Tensor, x2: Tensor, conv: resnet50.FoldedConv, act: int) -> Tensor:
+    """`act(w[:, :Cin] . x + w[:, Cin:] . x2[:, ::s, ::s] + bias)`: a bottleneck's conv3 with its projection shortcut folded
+    in (`isc_conv2d_nhwc_dual`; `conv.stride` is the shortcut's stride, `conv.weight` the two matrices side by side)."""
+    b, h, w, cin = x.shape
+    _, h2, w2, cin2 = x2.shape
+    cout = conv.weight.shape[0]
+    out = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
+    st = _lib.load().isc_conv2d_nhwc_dual(
+        x.data_ptr(), b, h, w, cin, x2.data_ptr(), h2, w2, cin2, conv.stride, conv.weight.data_ptr(), cout,
+        conv.bias.data_ptr(), None, act, out.data_ptr(), _lib.stream_handle(x.device),
+    )
+    _lib.check(st, "isc_conv2d_nhwc_dual")
+    return out
+
+
 class ResNet50Embedder(EmbeddingModule):
     """ResNet-50 trunk -> global average pool -> linear projection to `embedding_dim` (BASELINE.json config 2).
 
@@ -285,9 +300,12 @@ class ResNet50Embedder(EmbeddingModule):
                    "isc_maxpool_nhwc")
         y = pooled
         for blk in net.blocks:
-            identity = y if blk.downsample is None else _conv(y, blk.downsample, _lib.ISC_ACT_NONE)
             t = _conv(y, blk.conv1, _lib.ISC_ACT_RELU)
             t = _conv(t, blk.conv2, _lib.ISC_ACT_RELU)
+            if blk.fused is not None:  # the projection shortcut inside conv3 (resnet50.FUSED_SHORTCUT_STAGES)
+                y = _conv_dual(t, y, blk.fused, _lib.ISC_ACT_RELU)
+                continue
+            identity = y if blk.downsample is None else _conv(y, blk.downsample, _lib.ISC_ACT_NONE)
             y = _conv(t, blk.conv3, _lib.ISC_ACT_RELU, residual=identity)
         # tail in one launch: global average pool -> projection (-> F.normalize when predict_step asks for it)
         bb, hh, ww, cc = y.shape

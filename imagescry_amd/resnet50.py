@@ -95,17 +95,27 @@ def fold_conv_bn(sd: dict[str, Tensor], conv: str, bn: str, stride: int, pad: in
     return FoldedConv(w.float(), bias.float(), int(w.shape[1]), stride, pad)
 
 
+# Stages whose first block runs its projection shortcut INSIDE conv3 (`isc_conv2d_nhwc_dual`: the two 1 x 1 convolutions
+# K-concatenated, `relu(w3 . h + wd . x + b3 + bd)`), so the shortcut's [B, H, W, 4 * planes] map is never written and read
+# back as a residual.  Stage 1 is where that map is largest (1.6 GB at batch 512 / 224 px) and the two convolutions are
+# memory-bound: 660 + 834 us -> one launch; in stages 2 - 4 the same matrix work moves into a conv3 three to seven times as long
+# and the saving is the map's round trip only (measured: profiles/r04_resnet50_layers.txt).
+FUSED_SHORTCUT_STAGES = (1,)
+
+
 @dataclass
 class Bottleneck:
     conv1: FoldedConv
     conv2: FoldedConv
     conv3: FoldedConv
     downsample: FoldedConv | None
+    fused: FoldedConv | None = None  # conv3 and the shortcut side by side: weight [Cout, Cin3 + Cin_shortcut], bias b3 + bd
 
     def to(self, device: torch.device | str) -> "Bottleneck":
         return Bottleneck(
             self.conv1.to(device), self.conv2.to(device), self.conv3.to(device),
             None if self.downsample is None else self.downsample.to(device),
+            None if self.fused is None else self.fused.to(device),
         )
 
 
@@ -131,12 +141,19 @@ def fold_state_dict(sd: dict[str, Tensor]) -> FoldedResNet50:
             ds = None
             if f"{p}.downsample.0.weight" in sd:
                 ds = fold_conv_bn(sd, f"{p}.downsample.0", f"{p}.downsample.1", stride=s, pad=0)
+            conv3 = fold_conv_bn(sd, f"{p}.conv3", f"{p}.bn3", stride=1, pad=0)
+            fused = None
+            if ds is not None and li in FUSED_SHORTCUT_STAGES:
+                cout = conv3.weight.shape[0]
+                wcat = torch.cat([conv3.weight.reshape(cout, -1), ds.weight.reshape(cout, -1)], dim=1).contiguous()
+                fused = FoldedConv(wcat, (conv3.bias.double() + ds.bias.double()).float(), 1, s, 0)  # stride = the shortcut's
             blocks.append(
                 Bottleneck(
                     conv1=fold_conv_bn(sd, f"{p}.conv1", f"{p}.bn1", stride=1, pad=0),
                     conv2=fold_conv_bn(sd, f"{p}.conv2", f"{p}.bn2", stride=s, pad=1),
-                    conv3=fold_conv_bn(sd, f"{p}.conv3", f"{p}.bn3", stride=1, pad=0),
+                    conv3=conv3,
                     downsample=ds,
+                    fused=fused,
                 )
             )
     fcw = sd["fc.weight"].float()
@@ -186,9 +203,15 @@ def conv_bytes(batch: int, height: int, width: int, embedding_dim: int = 768) ->
             pin, pout = batch * h * w, batch * h2 * w2
             total += 4 * (pin * inplanes + pin * planes + planes * inplanes)  # conv1
             total += 4 * (pin * planes + pout * planes + planes * planes * 9)  # conv2
-            total += 4 * (pout * planes + 2 * pout * planes * EXPANSION + planes * EXPANSION * planes)  # conv3 + residual
-            if bi == 0 and (s != 1 or inplanes != planes * EXPANSION):  # downsample reads the strided input pixels
-                total += 4 * (pout * inplanes + pout * planes * EXPANSION + planes * EXPANSION * inplanes)
+            shortcut = bi == 0 and (s != 1 or inplanes != planes * EXPANSION)
+            fused = shortcut and (STAGES.index((planes, nblocks, stride)) + 1) in FUSED_SHORTCUT_STAGES
+            if fused:  # conv3 and the shortcut in one launch: both inputs and weights once, the output once, no residual
+                total += 4 * (pout * planes + pout * inplanes + pout * planes * EXPANSION
+                              + planes * EXPANSION * (planes + inplanes))
+            else:
+                total += 4 * (pout * planes + 2 * pout * planes * EXPANSION + planes * EXPANSION * planes)  # conv3 + residual
+                if shortcut:  # downsample reads the strided input pixels
+                    total += 4 * (pout * inplanes + pout * planes * EXPANSION + planes * EXPANSION * inplanes)
             inplanes = planes * EXPANSION
             h, w = h2, w2
     return total

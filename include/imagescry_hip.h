@@ -166,6 +166,17 @@ int isc_nchw_to_nhwc(const float* x, int B, int C, int H, int W, int Cpad, float
 int isc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S, int stride,
                     int pad, const float* bias, const float* residual, int act, float* out, void* stream);
 
+/* A 1 x 1 convolution over TWO inputs, K-concatenated:
+ *     out[b,h,w,:] = act( w[:, :Cin] . x[b,h,w,:] + w[:, Cin:] . x2[b, h*stride2, w*stride2, :] + bias [+ residual] )
+ * A ResNet bottleneck's projection shortcut folded into its last convolution (torchvision Bottleneck: `out = relu(
+ * bn3(conv3(h)) + downsample(x))`; the build's stand-in for the backbone call at src/imagescry/models/embedding.py:167-177):
+ * the shortcut's [B,H,W,Cout] map is never written and read back as a residual.
+ *   x   float [B,H,W,Cin], Cin % 32 == 0;  x2 float [B,H2,W2,Cin2], Cin2 % 32 == 0, (H2-1)/stride2+1 == H (same for W)
+ *   w   float [Cout, Cin + Cin2] (the two folded weight matrices side by side); bias = the sum of the two biases */
+int isc_conv2d_nhwc_dual(const float* x, int B, int H, int W, int Cin, const float* x2, int H2, int W2, int Cin2,
+                         int stride2, const float* w, int Cout, const float* bias, const float* residual, int act,
+                         float* out, void* stream);
+
 /* Same as isc_conv2d_nhwc with the input first multiplied by a per-(image, input channel) gate float [B, Cin]:
  * the squeeze-excitation scale of an MBConv block fused into its 1x1 projection convolution. */
 int isc_conv2d_nhwc_gated(const float* x, int B, int H, int W, int Cin, const float* gate, const float* w, int Cout, int R,

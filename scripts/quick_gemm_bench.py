@@ -32,3 +32,14 @@ for name, k, n, act, res in (("qkv", 768, 2304, 0, False), ("proj", 768, 768, 0,
     for _ in range(10): run()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
     print(f"{name:5s} M={m} K={k} N={n}: {dt*1e3:.3f} ms  {2*m*k*n/dt/1e12:.0f} TFLOP/s  ({2*m*k*n/dt/2.5e15:.3f} of peak)", flush=True)
+    if os.environ.get("GEMM_VENDOR_REF"):
+        # A known-good reference on the same device and the same random data (cdna_hip_programming.md rule 10: no ceiling
+        # claims from one's own attempts): the vendor library's plain fp16 GEMM of the shape, no bias / activation /
+        # residual -- MEASUREMENT ONLY, never a product path.
+        a2 = torch.randn(m, k, device=dev).half()
+        w2 = (torch.randn(n, k, device=dev) * 0.02).half()
+        for _ in range(3): torch.matmul(a2, w2.T)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): torch.matmul(a2, w2.T)
+        torch.cuda.synchronize(); dv = (time.perf_counter() - t0) / 10
+        print(f"      vendor fp16 GEMM (torch.matmul, fp16 out, no epilogue): {dv*1e3:.3f} ms  ({2*m*k*n/dv/2.5e15:.3f} of peak)", flush=True)

@@ -86,6 +86,47 @@ def test_conv2d_nhwc(b, h, w, cin, cout, k, stride, pad, epilogue, device: torch
     assert _rel_err(got, exp) < 1e-5
 
 
+@pytest.mark.parametrize(
+    "b,h,w,cin,cin2,cout,stride2",
+    [
+        (3, 56, 56, 64, 64, 256, 1),  # ResNet-50 layer1.0: conv3 + projection shortcut at one resolution, 64 x 256 ... tiles
+        (8, 130, 130, 64, 64, 256, 1),  # more tiles than resident workgroups, ragged last pixel tile
+        (2, 28, 28, 128, 256, 512, 2),  # layer2.0: the shortcut reads every second pixel of the 56 x 56 map
+        (1, 9, 7, 32, 96, 36, 3),  # one + three K steps, stride 3, Cout not a tile multiple, odd sizes
+    ],
+)
+def test_conv1x1_dual_input(b, h, w, cin, cin2, cout, stride2, device: torch.device) -> None:
+    """`isc_conv2d_nhwc_dual`: a bottleneck's last 1 x 1 convolution with its projection shortcut folded in, against
+    torch's `relu(conv3(t) + bias3 + downsample(x) + bias_d)` (torchvision Bottleneck.forward; the reference reaches its
+    backbone at src/imagescry/models/embedding.py:167-177).  K-concatenation changes the order of the float32 sum only."""
+    from imagescry_amd import _lib
+    from imagescry_amd.embedding import _conv_dual
+    from imagescry_amd.resnet50 import FoldedConv
+
+    g = cases.gen(b + cin + cin2 + cout)
+    h2, w2 = (h - 1) * stride2 + 1 + (stride2 > 1), (w - 1) * stride2 + 1  # (h2 - 1) // stride2 + 1 == h either way
+    t = torch.randn(b, cin, h, w, generator=g)
+    x = torch.randn(b, cin2, h2, w2, generator=g)
+    w3 = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    wd = torch.randn(cout, cin2, 1, 1, generator=g) / cin2 ** 0.5
+    b3, bd = torch.randn(cout, generator=g), torch.randn(cout, generator=g)
+    exp = F.relu(F.conv2d(t, w3, b3) + F.conv2d(x, wd, bd, stride=stride2))
+    fused = FoldedConv(torch.cat([w3.reshape(cout, cin), wd.reshape(cout, cin2)], dim=1).contiguous().to(device),
+                       (b3 + bd).to(device), 1, stride2, 0)
+    tn = t.permute(0, 2, 3, 1).contiguous().to(device)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(device)
+    got = _conv_dual(tn, xn, fused, _lib.ISC_ACT_RELU).permute(0, 3, 1, 2).cpu()
+    assert got.shape == exp.shape
+    assert _rel_err(got, exp) < 1e-5
+    # the shapes the kernel has no second-input form for are refused, not mis-computed
+    lib = _lib.load()
+    out = torch.empty((b, h, w, cout), device=device)
+    bad = lib.isc_conv2d_nhwc_dual(tn.data_ptr(), b, h, w, cin, xn.data_ptr(), h2 + stride2, w2, cin2, stride2,
+                                   fused.weight.data_ptr(), cout, fused.bias.data_ptr(), None, _lib.ISC_ACT_RELU,
+                                   out.data_ptr(), _lib.stream_handle(device))
+    assert bad == _lib.ISC_ERR_INVALID_ARG  # the second map does not cover the output grid at that stride
+
+
 def test_conv1x1_silu_and_residual_after_activation(device: torch.device) -> None:
     """A large short-K 1 x 1 layer with the EfficientNetV2 epilogues: SiLU, and `act(conv + bias) + residual`."""
     from imagescry_amd import _lib

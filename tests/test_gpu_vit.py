@@ -37,6 +37,10 @@ def _gen(seed: int) -> torch.Generator:
         (2049, 192, 2304, "none", False, False),  # 3 K steps (the minimum of the 256-tile kernel), fp16 output
         (5000, 64, 512, "gelu", False, False),  # ONE K step per tile on the streaming kernel, several tiles per chunk
         (70000, 128, 256, "none", True, True),  # 274 token tiles x one feature block: chunks of two tiles
+        # fp16 output over chunks of THREE tiles (the streaming kernel's spread epilogue: row blocks written at the tile
+        # boundary, held in registers across K steps of the next tile, and written in place during its first K step)
+        (150000, 192, 256, "none", False, False),  # 586 token tiles, 3 K steps per tile
+        (90000, 768, 512, "gelu", False, False),  # 352 token tiles x two feature blocks, 12 K steps, GELU
     ],
 )
 def test_gemm_f16(device, m, k, n, act, res, out_f32, layout):
