@@ -37,12 +37,16 @@
 // that a ds_read_b128 of an MFMA fragment (16 rows x 4 chunks per wave) is bank-conflict free; the LDS image is
 // lane-linear in the staging order (the swizzle is applied to the LDS-DMA source address).
 //
-// Two tile shapes share the kernel template:
+// Three tile shapes share the kernel template:
 //   TNQ = 256  256 bank rows x 256 queries per workgroup, waves 2 x 4 (128 x 64 each): the MFMA-bound shape for
 //              large query batches (arithmetic intensity 128 flop per staged byte);
 //   TNQ = 64   256 bank rows x  64 queries, waves 8 x 1 (32 x 64 each), a 4-deep ring for both operands: the
 //              HBM-bound shape for small query batches -- three 32 KiB bank blocks are in flight per CU while the
-//              matrix cores idle most of the time.
+//              matrix cores idle most of the time;
+//   TNQ = 128  256 bank rows x 128 queries, waves 4 x 2 (64 x 64 each), 3-deep rings (round 4): 64 < Q <= 128.  Two
+//              64-query tiles made every CU pull the bank twice through its L2 -> LDS path (3.7 ms at 10 M rows, one and a
+//              half times the 64-query search), the 256-query tile runs half empty; this one streams the bank once with
+//              the matrix pipe ~45 % busy.
 #include <math.h>
 #include <stdlib.h>
 
@@ -64,7 +68,7 @@ constexpr int CAP = 32;        // candidate slots per (segment, query); segment 
 constexpr int TARGET_WGS = 256;  // one workgroup per MI355X CU (the kernel uses all 160 KiB of LDS)
 constexpr int QCAP = 8192;  // candidates per query per level that the compact list / the selection can hold
 constexpr int SLACK = 6;
-constexpr int SMALL_Q = 128;  // up to this many queries the 64-query tile shape is used
+constexpr int SMALL_Q = 128;  // up to this many queries the HBM-bound tile shapes are used: 64 queries (Q <= 64) or 128
 constexpr int QBATCH = ISC_SEARCH_PASS_QUERIES;  // queries per pass: larger calls run as several passes over the same workspace
 constexpr int MAX_LEVELS = 12;
 constexpr int SEL_THREADS = 512;
@@ -85,7 +89,7 @@ struct Level {
 };
 
 struct Plan {
-    int tnq;             // queries per tile: 64 or 256
+    int tnq;             // queries per tile: 64, 128 or 256
     int segs_per_chunk;  // (8 / (tnq / 64)) row-block waves x 4 lane groups
     int kp;              // candidates carried per query (>= k + SLACK, multiple of 16)
     int nslots;          // level 0: per-query slots whose maxima bound the workgroup's kp-th score (0 = keep every score)
@@ -102,7 +106,7 @@ int plan_kp(int k) { return (int)isc_align_up((size_t)k + SLACK, 16); }
 #ifdef ISC_ABLATION
 int forced_tile() {
     static const int v = [] {
-        const char* e = getenv("ISC_FORCE_TILE");  // ablation builds only: 64 or 256
+        const char* e = getenv("ISC_FORCE_TILE");  // ablation builds only: 64, 128 or 256
         return e ? atoi(e) : 0;
     }();
     return v;
@@ -130,8 +134,8 @@ constexpr int first_ratio() { return 16; }
 Plan make_plan(int64_t n, int q, int k) {
     Plan p;
     p.qb = q < QBATCH ? q : QBATCH;
-    p.tnq = p.qb <= SMALL_Q ? 64 : 256;
-    if (forced_tile() == 64 || forced_tile() == 256) p.tnq = forced_tile();
+    p.tnq = p.qb <= 64 ? 64 : p.qb <= SMALL_Q ? 128 : 256;
+    if (forced_tile() == 64 || forced_tile() == 128 || forced_tile() == 256) p.tnq = forced_tile();
     p.segs_per_chunk = (8 / (p.tnq / 64)) * 4;
     p.kp = plan_kp(k);
     p.qtiles = isc_ceil_div(p.qb, p.tnq);
@@ -453,12 +457,13 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
     constexpr int B_TILE_BYTES = TNQ * 128;   // one K step of the query tile
     constexpr int NA = 4;                     // LDS-DMA instructions per thread per bank step (512 x 16 B x 4)
     constexpr int NB = B_TILE_BYTES / 8192;   // ... per query step: 4 or 1
-    constexpr int A_ST = TNQ == 256 ? 3 : 4;  // ring depths: together exactly 160 KiB
-    constexpr int B_ST = TNQ == 256 ? 2 : 4;
+    constexpr int A_ST = TNQ == 64 ? 4 : 3;  // ring depths: together exactly 160 KiB (TNQ = 128: 144 KiB)
+    constexpr int B_ST = TNQ == 256 ? 2 : TNQ == 128 ? 3 : 4;
     constexpr int DA = A_ST - 1;  // prefetch distances, in K steps
     constexpr int DB = B_ST - 1;
     constexpr int LDS_BYTES = A_ST * A_TILE_BYTES + B_ST * B_TILE_BYTES;
-    static_assert(LDS_BYTES == 163840, "the two rings fill the CU's LDS exactly");
+    static_assert(LDS_BYTES == (TNQ == 128 ? 147456 : 163840), "the two rings fill the CU's LDS (TNQ = 128: 144 KiB of it)");
+    static_assert(TNQ == 256 || DA == DB, "the HBM-bound shapes stage query and bank steps at one prefetch distance");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];  // the ONLY LDS object (see the guide)
 
     const int tid = threadIdx.x;
@@ -564,8 +569,8 @@ __global__ __launch_bounds__(NTHREADS) void k_dots_filter(const unsigned char* _
                 if (next + 1 < total_steps) wait_vmcnt<NA>();
                 else wait_vmcnt<0>();
             }
-        } else {  // stream order ... B(next) A(next) | B(next+1) A(next+1) | B(next+2) A(next+2)
-            const int ahead = min(2, total_steps - 1 - next);
+        } else {  // stream order ... B(next) A(next) | B(next+1) A(next+1) | B(next+2) A(next+2): DA - 1 groups stay in flight
+            const int ahead = min(DA - 1, total_steps - 1 - next);
             if (ahead >= 2) wait_vmcnt<2 * (NA + NB)>();
             else if (ahead == 1) wait_vmcnt<NA + NB>();
             else wait_vmcnt<0>();
@@ -1717,6 +1722,13 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const Filt
                        bank, l.r0, l.r1, l.tiles_per_chunk, l.ntiles, io.qpacked, ksteps, io.tau, p.qpad, w.seg_ent,  \
                        io.qcount, w.qlist, p.kp, nslots_arg, io.qflag, status, io.active)
     int nslots_arg = p.nslots;
+    if constexpr (TNQ == 128) {
+        // 64 < Q <= 128: always ONE query tile, so the bank stream is non-temporal (13) in the sample level, the filter
+        // levels and the redo (33) alike -- the only instantiations of this shape
+        if (l.sample) ISC_LAUNCH_FILTER(13, true);
+        else if (io.active) ISC_LAUNCH_FILTER(33, false);
+        else ISC_LAUNCH_FILTER(13, false);
+    } else {
     if (l.sample) {  // one tile per workgroup: the staging variant does not matter
 #ifdef ISC_ABLATION
         static const int abl = [] {
@@ -1783,6 +1795,7 @@ void launch_filter(const Level& l, const Plan& p, const Workspace& w, const Filt
             }
             break;
     }
+    }
 #undef ISC_LAUNCH_FILTER
 }
 
@@ -1844,6 +1857,7 @@ int run(const void* bank, int64_t n, int d, const void* queries, int q_total, in
             for_each_segment(l, p, [&](const Level& ls) {
                 isc_timing_begin(ISC_KERNEL_DOTS_FILTER, stream);
                 if (p.tnq == 256) launch_filter<T, 256>(ls, p, w, io, bank_bytes, ksteps, status, stream);
+                else if (p.tnq == 128) launch_filter<T, 128>(ls, p, w, io, bank_bytes, ksteps, status, stream);
                 else launch_filter<T, 64>(ls, p, w, io, bank_bytes, ksteps, status, stream);
                 isc_timing_end(ISC_KERNEL_DOTS_FILTER, stream);
             });
@@ -1881,6 +1895,7 @@ int run(const void* bank, int64_t n, int d, const void* queries, int q_total, in
             all.nchunks = isc_ceil_div(all.ntiles, all.tiles_per_chunk);
             for_each_segment(all, p, [&](const Level& ls) {
                 if (p.tnq == 256) launch_filter<T, 256>(ls, p, w, rio, bank_bytes, ksteps, status, stream);
+                else if (p.tnq == 128) launch_filter<T, 128>(ls, p, w, rio, bank_bytes, ksteps, status, stream);
                 else launch_filter<T, 64>(ls, p, w, rio, bank_bytes, ksteps, status, stream);
             });
             hipLaunchKernelGGL(k_final2<T>, dim3(q), dim3(SEL_THREADS), 0, stream, bank_bytes, ksteps, w.qpacked2, p.tnq, k,

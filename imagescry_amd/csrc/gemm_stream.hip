@@ -109,30 +109,9 @@ __device__ __forceinline__ void gs_mfma_half(const u32x4& a, const u32x4 (&b)[4]
 // the tile and nobody ever waits for them; the wm = 0 waves bunch theirs too and leave them in flight with a counted
 // wait.  (scripts/microbench/store_wall.hip: stores bunched behind a tile's MFMAs hide 60 % under the next tile, stores
 // interleaved with MFMAs cost ~150 cycles of matrix issue each, and what really exposes them is a later vmcnt wait.)
-// SPREAD (round 4; fp16 outputs of the SPLIT form): the 16 stores of a wave's finished tile no longer leave in one bunch.
-// A CU's vector-memory path takes loads and stores IN ORDER at ~12 B/clk; a 256 x 256 fp16 tile is 128 stores = ~11 k
-// cycles of that path, and bunched at the tile boundary they sit in front of the LDS-DMA pieces of the next K steps,
-// whose counted wait then starves the matrix pipe (the ring holds two K steps = ~6 k cycles of slack).  So the tile's
-// eight row blocks per wave are split three ways:
-//   NI  blocks are written at once, as before (2 NI x 8 stores per CU at the boundary);
-//   NH  blocks are converted to packed fp16 and HELD in registers (8 per block) -- their accumulators are free for the
-//       next tile -- and leave one block at a time at the START of K steps 2, 4, ... of the next tile (in front of that
-//       step's LDS-DMA pieces, so the step's ordinary counted wait covers them);
-//   the remaining ND = 8 - NI - NH blocks stay in their accumulators and are written during the next tile's FIRST K step,
-//       block m right before its first MFMA (the accumulator is consumed, then reused).
-// The path never sees more than ~4 k cycles of stores in one K step.  Held blocks cost registers (232 + 8 NH <= 256).
-#ifndef ISC_GS_NI
-#define ISC_GS_NI 2
-#endif
-#ifndef ISC_GS_NH
-#define ISC_GS_NH 3
-#endif
 template <int EPI, int DBG, bool SPLIT>
 __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmParams p) {
     constexpr int WN = 4, WM = 2, MB = 8;
-    constexpr int NI = ISC_GS_NI, NH = ISC_GS_NH, ND = MB - NI - NH;
-    static_assert(NI >= 0 && NH >= 0 && ND >= 0, "row blocks of a wave");
-    constexpr bool SPREAD = SPLIT && EPI != EPI_F32 && DBG == 0 && NI < MB;
     constexpr int LDS_BYTES = (A_ST + B_ST) * TILE_BYTES;
     static_assert(LDS_BYTES == 163840, "the two rings fill the CU's LDS exactly");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
@@ -314,39 +293,6 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
 #pragma unroll
         for (int n = 0; n < 4; ++n) c[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // SPREAD pieces: bias / activation / fp16 packing of one row block into two 16-byte registers, and their two stores
-    auto cvt_block = [&](f32x4 (&c)[4], u32x4 (&h)[2]) {
-#pragma unroll
-        for (int n = 0; n < 4; ++n) c[n] += bias[n];
-        if constexpr (EPI == EPI_F16_GELU) {
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) c[n][r] = gs_gelu(c[n][r]);
-        }
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const f32x4 lo = c[2 * hh], hi = c[2 * hh + 1];
-            h[hh] = __builtin_bit_cast(u32x4, half8{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3],
-                                                     (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]});
-        }
-#pragma unroll
-        for (int n = 0; n < 4; ++n) c[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    auto store_block = [&](const u32x4 (&h)[2], long long token) {
-        if (p.out_packed || token < p.M) {
-            _Float16* dst = reinterpret_cast<_Float16*>(p.out) +
-                            (p.out_packed ? gs_pk_offset(token, nb, p.N) : (size_t)token * p.N + nb);
-            *reinterpret_cast<u32x4*>(dst) = h[0];
-            *reinterpret_cast<u32x4*>(dst + 8) = h[1];
-        }
-    };
-    // K step (inside the next tile) at whose start held block j leaves: 2, 4, 6, ... (clamped to the tile's last step)
-    auto held_step = [&](int j) { return min(ksteps - 1, 2 + 2 * j); };
-    // counted waits of the wm = 0 waves assume unconditional stores (packed output) and tiles of at least three K steps;
-    // anything else drains
-    const bool counted = p.out_packed && ksteps >= 3;
-
     // fp16-output epilogues are DEFERRED: the finished tile's row block m is written out in the next K step of the
     // stream, right before that step's first MFMA on block m -- its conversions, GELU and stores then issue beside the
     // matrix work of the other blocks and of the SIMD's partner wave instead of holding the whole workgroup at the tile
@@ -360,19 +306,7 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
     int kt = 0, tile = 0;
     bool pend = false;        // wave-uniform: acc holds a finished tile whose epilogue has not run
     long long pend_row0 = 0;  // ... its first token row for this wave
-    u32x4 held[NH > 0 ? NH : 1][2];  // SPREAD: row blocks NI .. NI + NH - 1 of the previous tile, packed fp16
-    bool have_held = false;
-    long long held_row0 = 0;
     for (int step = 0; step < total_steps; ++step) {
-        if constexpr (SPREAD && NH > 0) {
-            // held blocks leave at the start of their K step, in front of this step's LDS-DMA pieces
-            if (have_held) {
-#pragma unroll
-                for (int j = 0; j < NH; ++j)
-                    if (kt == held_step(j)) store_block(held[j], held_row0 + (NI + j) * 16 + frow);
-                if (kt >= held_step(NH - 1)) have_held = false;
-            }
-        }
         const int sb = step + DB, sa = step + DA;
         const bool do_b = sb < total_steps && !(DBG == 4 && sb >= B_ST);
         const bool do_a = sa < total_steps;
@@ -398,7 +332,7 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
         GS_DS_READ(ar[1][0], a_addr0, 2048);
         GS_DS_READ(ar[1][1], a_addr1, 2048);
 #define GS_EPI(m_) \
-    if constexpr (DEFER || (SPREAD && (m_) >= NI + NH)) { if (pend) epi_block(acc[m_], pend_row0 + (m_) * 16 + frow); }
+    if constexpr (DEFER) { if (pend) epi_block(acc[m_], pend_row0 + (m_) * 16 + frow); }
 #define GS_DMA(j_)                                                                                  \
     if constexpr (SPLIT) {                                                                          \
         if constexpr (!STAGGER) { /* the wm = 0 loop: two pieces per row block */                   \
@@ -488,26 +422,12 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
 #undef GS_EPI
 
         bool drained = false;
-        const bool had_epi = (DEFER || (SPREAD && ND > 0)) && pend;
-        if constexpr (DEFER || SPREAD) pend = false;  // this step wrote the pending blocks out one by one
+        const bool had_epi = DEFER && pend;
+        if constexpr (DEFER) pend = false;  // this step wrote the pending tile out block by block
         if (++kt == ksteps) {
             kt = 0;
             const long long trow0 = (long long)(tile_begin + tile) * GT + wm * (GT / WM);
-            if constexpr (SPREAD) {
-#pragma unroll
-                for (int m = 0; m < NI; ++m) epi_block(acc[m], trow0 + m * 16 + frow);
-                if constexpr (NH > 0) {
-#pragma unroll
-                    for (int j = 0; j < NH; ++j) cvt_block(acc[NI + j], held[j]);
-                    have_held = true;
-                    held_row0 = trow0;
-                }
-                if constexpr (ND > 0) {
-                    pend = true;  // blocks NI + NH .. 7: written during the next step of the stream (or after the loop)
-                    pend_row0 = trow0;
-                }
-                drained = true;
-            } else if constexpr (DEFER) {
+            if constexpr (DEFER) {
                 pend = true;  // written out during the next step of the stream (or after the loop)
                 pend_row0 = trow0;
             } else {
@@ -521,26 +441,7 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
         // retire this wave's DMA for step + 1, then publish.  After a boundary epilogue everything is drained (its loads
         // and stores share the counter).  In a step that carried a deferred epilogue the newest operations are stores
         // and the bank pieces interleaved with them: the counted wait then retires more than it has to, never less.
-        if constexpr (SPREAD) {
-            // wm = 1: nothing to wait for (it issues no ring pieces and nobody waits for its stores).  wm = 0: retire the
-            // weight pieces of step + 1 and everything older; what was issued behind them may stay in flight --
-            //   tile-end step   [.. B x 8][A x 8][2 NI stores]
-            //   the step after  blocks 0 - 3: [B pair][2 stores if deferred]; blocks 4 - 7: [A pair][2 stores if deferred]:
-            //                   behind the last weight piece sit the stores of the deferred blocks m >= 3 and the A pieces
-            if (wm == 0) {
-                constexpr int ND3 = MB - (NI + NH > 3 ? NI + NH : 3);
-                if (!counted || step + 2 >= total_steps) {
-                    if (drained || had_epi) gs_wait_vmcnt<0>();
-                    else retire_for(step + 1);
-                } else if (drained) {
-                    gs_wait_vmcnt<2 * NA + 2 * NI>();
-                } else if (had_epi) {
-                    gs_wait_vmcnt<2 * NA + 2 * ND3>();
-                } else {
-                    retire_for(step + 1);
-                }
-            }
-        } else if (drained && SPLIT) {
+        if (drained && SPLIT) {
             // the tile's stores were issued just now, behind this step's ring pieces.  wm = 1: nothing to wait for.  wm = 0,
             // packed fp16 output (two unconditional stores per row block): leave the 16 stores and the 8 token pieces
             // of step + 2 in flight; otherwise (float32 output: residual loads, predicated stores) drain.
@@ -565,20 +466,6 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16_stream(const StreamGemmPa
         if (pend) {
 #pragma unroll
             for (int m = 0; m < MB; ++m) epi_block(acc[m], pend_row0 + m * 16 + frow);
-        }
-    }
-    if constexpr (SPREAD) {  // the last tile of the chunk: what is still held or pending
-        if constexpr (NH > 0) {
-            if (have_held) {
-#pragma unroll
-                for (int j = 0; j < NH; ++j) store_block(held[j], held_row0 + (NI + j) * 16 + frow);
-            }
-        }
-        if constexpr (ND > 0) {
-            if (pend) {
-#pragma unroll
-                for (int m = NI + NH; m < MB; ++m) epi_block(acc[m], pend_row0 + m * 16 + frow);
-            }
         }
     }
     };

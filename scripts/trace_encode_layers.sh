@@ -23,6 +23,7 @@ def conv_launches(m, kk, cout, resident=512):
         return 2 if rounds > 0 else 1
     return 1
 B = 512
+FUSED_SHORTCUT_STAGES = (1,)
 layers = []  # (name, pixels_out, cin*k*k, cout, in_bytes, out_bytes, res_bytes)
 def out(n, k, s, p): return (n + 2 * p - k) // s + 1
 h = w = out(224, 7, 2, 3)
@@ -34,18 +35,23 @@ for li, (planes, nb, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2),
         s = stride if bi == 0 else 1
         h2 = out(h, 3, s, 1)
         px_in, px_out = B * h * h, B * h2 * h2
-        if bi == 0:
+        fused = bi == 0 and li in FUSED_SHORTCUT_STAGES  # resnet50.FUSED_SHORTCUT_STAGES: the shortcut runs inside conv3
+        if bi == 0 and not fused:
             layers.append((f"l{li}.{bi}.down 1x1/{s}", px_out, inpl, planes * 4, px_in * inpl * 4, px_out * planes * 16, 0))
         layers.append((f"l{li}.{bi}.conv1 1x1", px_in, inpl, planes, px_in * inpl * 4, px_in * planes * 4, 0))
         layers.append((f"l{li}.{bi}.conv2 3x3/{s}", px_out, planes * 9, planes, px_in * planes * 4, px_out * planes * 4, 0))
-        layers.append((f"l{li}.{bi}.conv3 1x1+res", px_out, planes, planes * 4, px_out * planes * 4, px_out * planes * 16, px_out * planes * 16))
+        if fused:
+            layers.append((f"l{li}.{bi}.conv3+shortcut", px_out, planes + inpl, planes * 4,
+                           px_out * (planes + inpl) * 4, px_out * planes * 16, 0))
+        else:
+            layers.append((f"l{li}.{bi}.conv3 1x1+res", px_out, planes, planes * 4, px_out * planes * 4, px_out * planes * 16, px_out * planes * 16))
         inpl = planes * 4
         h = h2
 # (the projection head is no longer a k_conv_f32 launch: k_pool_linear_l2norm, reported below)
 import os
 f = max(glob.glob("gpurun_out/prof_enc/*/*kernel_trace.csv"), key=os.path.getmtime)
 rows = [r for r in csv.DictReader(open(f)) if "k_conv_f32" in r["Kernel_Name"] or "k_conv1x1_f32_stream" in r["Kernel_Name"]]
-need = [conv_launches(m, k, nn) for (name, m, k, nn, ib, ob, rb) in layers]
+need = [1 if "shortcut" in name else conv_launches(m, k, nn) for (name, m, k, nn, ib, ob, rb) in layers]
 last = rows[-sum(need):]
 merged, pos = [], 0
 for cnt in need:

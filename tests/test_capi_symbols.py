@@ -101,8 +101,8 @@ def test_host_only_entry_points(library: ctypes.CDLL) -> None:
 
 def test_production_library_holds_no_ablation_kernels(library: ctypes.CDLL) -> None:
     """The shipped library contains exactly one `k_dots_filter` per (dtype, tile shape, staging variant, level kind)
-    that the search launches -- f16 / f32 x {64-query tile: filter and sample, each with the default and the non-temporal bank stream; 256-query tile: split,
-    unsplit, sample} --
+    that the search launches -- f16 / f32 x {64-query tile: filter and sample, each with the default and the non-temporal bank stream; 128-query tile:
+    filter and sample (non-temporal); 256-query tile: split, unsplit, sample} --
     and nothing else: the wrong-result ablation variants only exist in -DISC_ABLATION builds, and no environment
     variable changes which kernel runs."""
     import shutil
@@ -119,7 +119,10 @@ def test_production_library_holds_no_ablation_kernels(library: ctypes.CDLL) -> N
     expect = sorted((t, str(tnq), str(dbg), sample) for t in ("DF16_", "f")
                     for tnq, dbg, sample in ((64, 12, "0"), (64, 13, "0"), (64, 12, "1"), (64, 13, "1"), (256, 0, "0"),
                                              (256, 12, "0"), (256, 12, "1"), (64, 32, "0"), (64, 33, "0"), (256, 20, "0"),
-                                             (256, 32, "0")))
+                                             (256, 32, "0"),
+                                             # the 128-query tile (64 < Q <= 128, always one query tile): non-temporal
+                                             # stream in the sample and filter levels, its redo form
+                                             (128, 13, "0"), (128, 13, "1"), (128, 33, "0")))
     assert variants == expect
     gemm = sorted(set(re.findall(r"k_gemm_f16_(dma|big)ILi(\d+)E", out)))
     assert gemm == [("big", "0"), ("dma", "0")]

@@ -69,6 +69,15 @@ def test_exact_ties_go_to_the_lowest_index(dtype: torch.dtype, tag: str, device:
         (40000, 192, 513, 10, torch.float16),
         (30000, 100, 700, 7, torch.float32),
         (16000, 768, 1024, 10, torch.float16),
+        # the 128-query tile (64 < Q <= 128: waves 4 x 2, 3-deep rings): full and ragged query tiles, three levels, an fp32
+        # bank with a padded K step, k past the 64-candidate lists; and the query counts around it -- 192 / 384 / 512
+        (70000, 768, 128, 10, torch.float16),
+        (266241, 64, 100, 10, torch.float16),
+        (30000, 100, 65, 7, torch.float32),
+        (50000, 256, 127, 70, torch.float16),
+        (60000, 768, 192, 10, torch.float16),
+        (30000, 384, 384, 10, torch.float16),
+        (20000, 768, 512, 10, torch.float16),
     ],
 )
 def test_search_matches_oracle(n: int, d: int, q: int, k: int, dtype: torch.dtype, device: torch.device) -> None:
