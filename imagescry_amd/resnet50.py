@@ -96,11 +96,12 @@ def fold_conv_bn(sd: dict[str, Tensor], conv: str, bn: str, stride: int, pad: in
 
 
 # Stages whose first block runs its projection shortcut INSIDE conv3 (`isc_conv2d_nhwc_dual`: the two 1 x 1 convolutions
-# K-concatenated, `relu(w3 . h + wd . x + b3 + bd)`), so the shortcut's [B, H, W, 4 * planes] map is never written and read
-# back as a residual.  Stage 1 is where that map is largest (1.6 GB at batch 512 / 224 px) and the two convolutions are
-# memory-bound: 660 + 834 us -> one launch; in stages 2 - 4 the same matrix work moves into a conv3 three to seven times as long
-# and the saving is the map's round trip only (measured: profiles/r04_resnet50_layers.txt).
-FUSED_SHORTCUT_STAGES = (1,)
+# K-concatenated, `relu(w3 . h + wd . x[:, ::s, ::s] + b3 + bd)`), so the shortcut's [B, H, W, 4 * planes] map is never
+# written and read back as a residual.  Stage 1 gains most -- the map is largest there (1.6 GB at batch 512 / 224 px) and both
+# convolutions are memory-bound: 660 + 834 us -> 1 056 us in one launch; in stages 2 - 4 the same matrix work moves into a
+# conv3 three to seven times as long and the saving is the map's round trip and a launch.  Same-device A/B of the whole step
+# (gpurun_out/r4/call6.out, batch 512): no stage 41.2 ms, stage 1 40.75, stages 1 - 2 40.55, 1 - 3 40.45, all four 40.35.
+FUSED_SHORTCUT_STAGES = (1, 2, 3, 4)
 
 
 @dataclass

@@ -123,6 +123,35 @@ def f_conv():
            f"b{b} {h}x{w} cin{cin} cout{cout} k{k} s{stride} p{pad} {act_name} res={res_mode}: rel err {err:.3g}")
 
 
+def f_conv_dual():
+    """isc_conv2d_nhwc_dual: a bottleneck's conv3 with its projection shortcut K-concatenated (any stride of the shortcut)."""
+    from imagescry_amd.embedding import _conv_dual
+    b = int(rng.integers(1, 5))
+    h, w = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+    if rng.random() < 0.2:  # more tiles than resident workgroups
+        b, h, w = int(rng.integers(2, 7)), int(rng.integers(60, 150)), int(rng.integers(60, 150))
+    cin, cin2 = int(rng.choice([32, 64, 96, 128, 256])), int(rng.choice([32, 64, 160, 256, 512]))
+    cout = int(rng.choice([4, 36, 64, 100, 128, 192, 256, 512]))
+    s2 = int(rng.choice([1, 1, 2, 3]))
+    h2, w2 = (h - 1) * s2 + 1 + int(rng.integers(0, s2)), (w - 1) * s2 + 1 + int(rng.integers(0, s2))
+    g = gen()
+    t = torch.randn(b, cin, h, w, generator=g)
+    x = torch.randn(b, cin2, h2, w2, generator=g)
+    w3 = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    wd = torch.randn(cout, cin2, 1, 1, generator=g) / cin2 ** 0.5
+    b3, bd = torch.randn(cout, generator=g), torch.randn(cout, generator=g)
+    act_name = str(rng.choice(["none", "relu", "silu"]))
+    fn = {"none": lambda z: z, "relu": F.relu, "silu": F.silu}[act_name]
+    exp = fn(F.conv2d(t, w3, b3) + F.conv2d(x, wd, bd, stride=s2))
+    fused = FoldedConv(torch.cat([w3.reshape(cout, cin), wd.reshape(cout, cin2)], dim=1).contiguous().to(dev),
+                       (b3 + bd).to(dev), 1, s2, 0)
+    got = _conv_dual(t.permute(0, 2, 3, 1).contiguous().to(dev), x.permute(0, 2, 3, 1).contiguous().to(dev), fused,
+                     {"none": 0, "relu": 1, "silu": 3}[act_name]).permute(0, 3, 1, 2).cpu()
+    err = float((got - exp).abs().max() / exp.abs().max().clamp_min(1e-30))
+    report("conv_dual", got.shape == exp.shape and err < 2e-5,
+           f"b{b} {h}x{w} cin{cin}+{cin2} ({h2}x{w2}/{s2}) cout{cout} {act_name}: rel err {err:.3g}")
+
+
 def f_gemm():
     m = int(rng.choice([1, 7, 128, 129, 255, 300, 513, 1100]))
     k = int(rng.choice([64, 128, 192, 320, 768]))
@@ -160,7 +189,7 @@ def f_gemm():
 
 
 def f_attention():
-    b, t, heads = int(rng.integers(1, 4)), int(rng.choice([1, 2, 15, 16, 17, 50, 197, 223, 224])), int(rng.integers(1, 5))
+    b, t, heads = int(rng.integers(1, 4)), int(rng.choice([1, 2, 15, 16, 17, 50, 191, 192, 193, 197, 207, 208, 209, 223, 224])), int(rng.integers(1, 5))
     pk = bool(rng.random() < 0.5)
     d = heads * 64
     g = gen()
@@ -358,7 +387,7 @@ def f_pca_fit():
     report("pca_fit", ok, f"n{n} f{f} kmax{kmax} max ev err {(got - want).abs().max():.3g}")
 
 
-for name, fn in (("head", f_head), ("pca_fit", f_pca_fit), ("normalize", f_normalize), ("resize", f_resize), ("conv", f_conv), ("gemm", f_gemm),
+for name, fn in (("head", f_head), ("pca_fit", f_pca_fit), ("normalize", f_normalize), ("resize", f_resize), ("conv", f_conv), ("conv_dual", f_conv_dual), ("gemm", f_gemm),
                  ("attention", f_attention), ("layernorm", f_layernorm), ("dwconv", f_dwconv),
                  ("gated conv + linear_centered", f_gated_and_centered), ("pools + l2norm", f_pools_l2norm), ("merge", f_merge)):
     if only is None or any(o in name for o in only):

@@ -7,6 +7,9 @@ from imagescry_amd import EfficientNetEmbedder, ImageBatch, ResNet50Embedder, Vi
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "effnet_s"
 b = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+if len(sys.argv) > 3:  # resnet50 only: stages whose projection shortcut runs inside conv3, e.g. "1,2" (A/B aid)
+    from imagescry_amd import resnet50
+    resnet50.FUSED_SHORTCUT_STAGES = tuple(int(v) for v in sys.argv[3].split(",") if v)
 model = (ResNet50Embedder() if which == "resnet50" else ViTB16Embedder() if which == "vit_b16"
          else EfficientNetEmbedder(backbone_size=which.split("_")[1])).to(dev)
 kid = _lib.ISC_KERNEL_GEMM_F16 if which == "vit_b16" else _lib.ISC_KERNEL_CONV

@@ -23,7 +23,7 @@ def conv_launches(m, kk, cout, resident=512):
         return 2 if rounds > 0 else 1
     return 1
 B = 512
-FUSED_SHORTCUT_STAGES = (1,)
+FUSED_SHORTCUT_STAGES = (1, 2, 3, 4)
 layers = []  # (name, pixels_out, cin*k*k, cout, in_bytes, out_bytes, res_bytes)
 def out(n, k, s, p): return (n + 2 * p - k) // s + 1
 h = w = out(224, 7, 2, 3)

@@ -69,6 +69,30 @@ def test_fit_and_transform_match_oracle(n: int, f: int, kmax, device: torch.devi
         pca.transform(x)  # CPU tensor: no fallback
 
 
+@pytest.mark.parametrize("threshold", [0.9, 0.99, 0.999])
+def test_uncapped_component_count_on_a_decaying_spectrum_and_host_samples(threshold: float, device: torch.device) -> None:
+    """No cap on the components, F = 96, a geometric spectrum: the count the threshold asks for equals the reference
+    rule's on the SVD (decomposition.py:124-136) -- the explained-variance ratios and their cumulative sum are float32 on
+    both sides.  (At a threshold of exactly 1.0 the count hangs on the last ulp of a float32 cumsum in the reference too;
+    the Gram route's eigenvalues below ~1e-7 of the largest are rounding noise, which is the accuracy floor of that tail.)
+    The call shape is the reference's: `PCA(...).fit(host_samples)` on a model that has not been placed."""
+    from imagescry_amd import PCA
+
+    g = cases.gen(96)
+    n, f = 3000, 96
+    basis, _ = torch.linalg.qr(torch.randn(f, f, generator=g))
+    x = (torch.randn(n, f, generator=g) * (0.9 ** torch.arange(f, dtype=torch.float32))) @ basis.T + 3.0
+    ref = decomposition_oracle.fit(x, min_explained_variance=threshold)
+    pca = PCA(min_explained_variance=threshold).fit(x)  # host samples: copied to the current HIP device
+    assert pca.device.type == "cuda" and pca.fitted
+    assert pca.num_components == ref.num_components, (pca.num_components, ref.num_components)
+    assert 1 < pca.num_components < f
+    assert pca.explained_variance.dtype == torch.float32
+    torch.testing.assert_close(pca.explained_variance.cpu(), ref.explained_variance, rtol=2e-3, atol=1e-7)
+    assert repr(pca) == f"PCA(num_features={f}, num_components={ref.num_components})"
+    assert repr(PCA()) == "PCA(num_features=not fitted, num_components=not fitted)"
+
+
 def _reference_features(correlated: bool) -> torch.Tensor:
     from torch.distributions import MultivariateNormal
 
