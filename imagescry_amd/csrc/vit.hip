@@ -569,12 +569,14 @@ void launch_layernorm(int nv, dim3 grid, hipStream_t s, const float* x, long lon
 //                                       to keys is free as long as both operands agree: slot (g, j) <-> key
 //                                       32 ks + 4 g + j (j < 4) or 32 ks + 16 + 4 g + (j - 4).  With that mapping the
 //                                       P^T operand is exactly what the lane already holds after the softmax, so the
-//                                       probabilities never leave registers; V^T is stored with its columns in that
-//                                       order, one 16-byte LDS load per fragment.
+//                                       probabilities never leave registers; the values stay row-major in LDS and the
+//                                       V^T fragments come out of two transposed reads (ds_read_b64_tr_b16) each.
 constexpr int ATT_TMAX = 224;
 constexpr int ATT_KSTRIDE = 72;   // halves per key row (64 + 8 pad)
-constexpr int ATT_VSTRIDE = 232;  // halves per value^T row (224 + 8 pad)
+constexpr int ATT_VSTRIDE = 72;   // halves per value row (row-major, like the keys; read transposed by ds_read_b64_tr_b16)
 constexpr int ATT_THREADS = 512;
+typedef short tr4 __attribute__((__vector_size__(4 * sizeof(short))));  // what ds_read_b64_tr_b16 returns: four 16-bit values
+typedef short tr8 __attribute__((__vector_size__(8 * sizeof(short))));
 
 // NKB = key blocks of 16 the kernel computes (T <= 16 NKB).  TAIL: T > 16 (NKB - 1), so only the LAST key block holds
 // keys past T and only it is masked -- the shape of every ViT launch (T = 197: NKB = 13, the fourteenth block, which is
@@ -585,12 +587,15 @@ constexpr int ATT_THREADS = 512;
 // loop -- feeding v_exp_f32 directly, instead of a subtraction, a multiplication and the exponential; the masks shrink
 // from two instructions per score to two per score of ONE block.  Per 16-query block: ~230 vector instructions instead
 // of ~390 (28 K-fragment reads, 26 + 28 MFMAs).
+#ifdef ISC_ABLATION
+__device__ int g_att_abl = 0;  // ISC_ATT_ABL (timing aid, wrong results): 1 = stage keys / values only, 2 = no staging loads
+#endif
 template <bool PACKED, int NKB, bool TAIL>
 __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* __restrict__ qkv, int T, int heads,
                                                                 _Float16* __restrict__ out) {
     static_assert(NKB >= 1 && NKB <= ATT_TMAX / 16, "key blocks");
     __shared__ __attribute__((aligned(16))) _Float16 Ks[ATT_TMAX * ATT_KSTRIDE];
-    __shared__ __attribute__((aligned(16))) _Float16 Vt[64 * ATT_VSTRIDE];
+    __shared__ __attribute__((aligned(16))) _Float16 Vs[ATT_TMAX * ATT_VSTRIDE];
     const int b = blockIdx.x / heads;
     const int h = blockIdx.x - b * heads;
     const int D = heads * 64;
@@ -609,20 +614,24 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
         const int t = i >> 3, c = i & 7;
         half8 kv = half8{0, 0, 0, 0, 0, 0, 0, 0};
         half8 vv = kv;
+#ifdef ISC_ABLATION
+        if (t < T && !(g_att_abl & 2)) {
+#else
         if (t < T) {
+#endif
             kv = *reinterpret_cast<const half8*>(qkv_at(t, 1, c));
             vv = *reinterpret_cast<const half8*>(qkv_at(t, 2, c));
         }
         *reinterpret_cast<half8*>(&Ks[t * ATT_KSTRIDE + c * 8]) = kv;
-        // value^T columns are stored in the order the P^T operand holds its keys: inside every group of 32 keys, key
-        // 4 g + j (j < 4) sits at column 8 g + j and key 16 + 4 g + j at column 8 g + 4 + j, so the eight values a lane
-        // feeds to one MFMA are 16 contiguous bytes (one ds_read_b128 instead of a ds_read2_b64 at twice the LDS cycles)
-        const int u = t & 31;
-        const int tp = (t & ~31) + ((u & 12) << 1) + ((u & 16) >> 2) + (u & 3);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * ATT_VSTRIDE + tp] = vv[j];
+        // values stay ROW-major, one 16-byte LDS store per chunk like the keys: the transposition the V^T operand needs is
+        // done by the reads (ds_read_b64_tr_b16).  Round 3 scattered eight 2-byte stores per chunk into a transposed image
+        // -- with any 16-byte-aligned row stride all eight land in ONE bank (8 rows x stride = 0 mod 32 dwords).
+        *reinterpret_cast<half8*>(&Vs[t * ATT_VSTRIDE + c * 8]) = vv;
     }
     __syncthreads();
+#ifdef ISC_ABLATION
+    if (g_att_abl & 1) return;
+#endif
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -717,7 +726,13 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
             }
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const half8 vf = *reinterpret_cast<const half8*>(&Vt[(db * 16 + qi) * ATT_VSTRIDE + ks * 32 + g * 8]);
+                // V^T fragment: slot j of lane group g is key 32 ks + 4 g + j (j < 4) / 32 ks + 16 + 4 g + (j - 4), of value
+                // column 16 db + qi.  One transposed read hands every lane of a 16-lane group ITS column of a 4-row block;
+                // lane 4 q + p of the group supplies the address of row q, columns 4 p .. 4 p + 3 (EXEC is all ones here).
+                const _Float16* vb = &Vs[(ks * 32 + g * 4 + (qi >> 2)) * ATT_VSTRIDE + db * 16 + (qi & 3) * 4];
+                const tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)vb);
+                const tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)(vb + 16 * ATT_VSTRIDE));
+                const half8 vf = __builtin_bit_cast(half8, tr8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
                 o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[db], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -904,6 +919,13 @@ extern "C" int isc_attention_f16(const void* qkv, int B, int T, int heads, int h
     if (head_dim != 64 || T > ATT_TMAX) return ISC_ERR_UNSUPPORTED;
     if (!isc_aligned(qkv, 16) || !isc_aligned(out, 16)) return ISC_ERR_ALIGNMENT;
     if ((long long)B * heads > 0x7fffffffLL) return ISC_ERR_UNSUPPORTED;
+#ifdef ISC_ABLATION
+    static const bool att_abl_set = [] {
+        const int v = getenv("ISC_ATT_ABL") ? atoi(getenv("ISC_ATT_ABL")) : 0;
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_att_abl), &v, sizeof(int)) == hipSuccess;
+    }();
+    (void)att_abl_set;
+#endif
 #define ISC_ATT_LAUNCH(PK_, NKB_, TAIL_)                                                                              \
     hipLaunchKernelGGL((k_attention_f16<PK_, NKB_, TAIL_>), dim3((unsigned)(B * heads)), dim3(ATT_THREADS), 0,          \
                        isc_stream(stream), reinterpret_cast<const _Float16*>(qkv), T, heads,                            \
