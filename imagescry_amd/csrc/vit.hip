@@ -610,23 +610,36 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
     };
 
     constexpr int TROWS = NKB * 16 < ATT_TMAX ? (NKB + (NKB & 1)) * 16 : ATT_TMAX;  // key rows staged (whole MFMA k-steps of 32)
-    for (int i = tid; i < TROWS * 8; i += ATT_THREADS) {
+    // staging: ALL of a thread's key / value chunks are requested before the first one is waited for (as a rolled loop the
+    // compiler waits for each pair of loads before it issues the next: four dependent HBM round trips per workgroup)
+    constexpr int SROUNDS = (TROWS * 8 + ATT_THREADS - 1) / ATT_THREADS;
+    half8 kreg[SROUNDS], vreg[SROUNDS];
+#pragma unroll
+    for (int r = 0; r < SROUNDS; ++r) {
+        const int i = tid + r * ATT_THREADS;
         const int t = i >> 3, c = i & 7;
-        half8 kv = half8{0, 0, 0, 0, 0, 0, 0, 0};
-        half8 vv = kv;
+        kreg[r] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        vreg[r] = kreg[r];
 #ifdef ISC_ABLATION
         if (t < T && !(g_att_abl & 2)) {
 #else
         if (t < T) {
 #endif
-            kv = *reinterpret_cast<const half8*>(qkv_at(t, 1, c));
-            vv = *reinterpret_cast<const half8*>(qkv_at(t, 2, c));
+            kreg[r] = *reinterpret_cast<const half8*>(qkv_at(t, 1, c));
+            vreg[r] = *reinterpret_cast<const half8*>(qkv_at(t, 2, c));
         }
-        *reinterpret_cast<half8*>(&Ks[t * ATT_KSTRIDE + c * 8]) = kv;
-        // values stay ROW-major, one 16-byte LDS store per chunk like the keys: the transposition the V^T operand needs is
-        // done by the reads (ds_read_b64_tr_b16).  Round 3 scattered eight 2-byte stores per chunk into a transposed image
-        // -- with any 16-byte-aligned row stride all eight land in ONE bank (8 rows x stride = 0 mod 32 dwords).
-        *reinterpret_cast<half8*>(&Vs[t * ATT_VSTRIDE + c * 8]) = vv;
+    }
+#pragma unroll
+    for (int r = 0; r < SROUNDS; ++r) {
+        const int i = tid + r * ATT_THREADS;
+        const int t = i >> 3, c = i & 7;
+        if (i < TROWS * 8) {
+            *reinterpret_cast<half8*>(&Ks[t * ATT_KSTRIDE + c * 8]) = kreg[r];
+            // values stay ROW-major, one 16-byte LDS store per chunk like the keys: the transposition the V^T operand needs
+            // is done by the reads (ds_read_b64_tr_b16).  Round 3 scattered eight 2-byte stores per chunk into a transposed
+            // image -- with any 16-byte-aligned row stride all eight land in ONE bank (8 rows x stride = 0 mod 32 dwords).
+            *reinterpret_cast<half8*>(&Vs[t * ATT_VSTRIDE + c * 8]) = vreg[r];
+        }
     }
     __syncthreads();
 #ifdef ISC_ABLATION
