@@ -270,7 +270,7 @@ class EmbeddingBank:
 
     def _workspace(self, n_queries: int, k: int, lane: int = -1) -> Tensor:
         """The search workspace.  The C side runs a call as passes of at most `ISC_SEARCH_PASS_QUERIES` queries over
-        one workspace and cuts the queries into tiles of 64 (up to 128 queries) or 256, so the size depends on
+        one workspace and cuts the queries into ONE tile of 64 (Q <= 64) or 128 (Q <= 128), or tiles of 256, so the size depends on
         (padded queries of a pass, k) only: alternating batch sizes inside one bucket -- a pipeline's short last
         batch -- reuse one allocation instead of reallocating 150-300 MB per call.  One buffer per bucket and lane is kept."""
         nq = min(n_queries, _lib.ISC_SEARCH_PASS_QUERIES)
