@@ -1029,6 +1029,15 @@ static constexpr bool conv_one_tile_per_wg() { return false; }
 #endif
 
 #ifdef ISC_ABLATION
+static bool conv_no_halo() {
+    static const bool v = getenv("ISC_CONV_NO_HALO") != nullptr;  // A/B aid: small-channel layers on k_conv_f32's packed-K mode
+    return v;
+}
+#else
+static constexpr bool conv_no_halo() { return false; }
+#endif
+
+#ifdef ISC_ABLATION
 static bool conv_no_split() {
     static const bool v = getenv("ISC_CONV_NO_SPLIT") != nullptr;  // A/B aid: no half-tile remainder launch
     return v;
@@ -1036,6 +1045,12 @@ static bool conv_no_split() {
 #else
 static constexpr bool conv_no_split() { return false; }
 #endif
+
+// conv_halo.hip: small-channel R x R layers with the pixel operand gathered from an input halo tile in LDS
+bool isc_conv_halo_applies(int Cin, int Cout, int R, int S, int stride, int pad, bool has_sub_or_scale, size_t* lds_bytes);
+int isc_conv_halo_launch(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S, int stride,
+                         int pad, int Ho, int Wo, const float* bias, const float* residual, int act, int res_after_act,
+                         float* out, hipStream_t stream);
 
 struct ConvSecondInput {  // see ConvParams::x2
     const float* x2 = nullptr;
@@ -1075,6 +1090,19 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     if (!isc_aligned(x, 16) || !isc_aligned(w, 16) || !isc_aligned(out, 16) || (bias && !isc_aligned(bias, 16)) ||
         (residual && !isc_aligned(residual, 16)))
         return ISC_ERR_ALIGNMENT;
+    // the RGB stems and EfficientNetV2's 24-channel stage: pixel operand from an input halo tile in LDS (conv_halo.hip)
+    if (tap4 && !second.x2 && !conv_no_halo() && M * Cout < (1ll << 31) &&
+        isc_conv_halo_applies(Cin, Cout, R, S, stride, pad, sub != nullptr || scale != nullptr, nullptr)) {
+        if (!isc_aligned(x, 16) || !isc_aligned(w, 16) || !isc_aligned(out, 16) || (bias && !isc_aligned(bias, 16)) ||
+            (residual && !isc_aligned(residual, 16)))
+            return ISC_ERR_ALIGNMENT;
+        hipStream_t hs = isc_stream(stream);
+        isc_timing_begin(ISC_KERNEL_CONV, hs);
+        const int st = isc_conv_halo_launch(x, B, H, W, Cin, w, Cout, R, S, stride, pad, Ho, Wo, bias, residual, act,
+                                            res_after_act, out, hs);
+        isc_timing_end(ISC_KERNEL_CONV, hs);
+        return st;
+    }
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.res = residual; p.sub = sub; p.scale = scale; p.out = out;
     p.x2 = second.x2; p.x2_step0 = x2_step0; p.H2 = second.H2; p.W2 = second.W2; p.Cin2 = second.Cin2; p.stride2 = second.stride2;

@@ -24,7 +24,7 @@ def total(sub: str, counter: str) -> tuple[float, int]:
     files = sorted(glob.glob(str(src / sub / "*/*counter_collection.csv")), key=lambda f: Path(f).stat().st_mtime, reverse=True)
     s, n = 0.0, 0
     for r in csv.DictReader(open(files[0])):
-        if "k_conv_f32" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if ("k_conv_f32" in r["Kernel_Name"] or "k_conv_halo_f32" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
             s += float(r["Counter_Value"])
             n += 1
     return s, n

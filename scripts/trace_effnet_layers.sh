@@ -56,7 +56,7 @@ for si, blocks in enumerate(E.block_specs("s"), 1):
         h = h2
 layers.append(("head 1x1", "conv", B * h * h, 256, 1280, B * h * h * (256 + 1280) * 4))
 f = max(glob.glob("gpurun_out/prof_eff_layers/*/*kernel_trace.csv"), key=os.path.getmtime)
-pat = {"conv": ("k_conv_f32", "k_conv1x1_f32_stream"), "dw": ("k_dwconv",), "pool": ("k_global_avgpool",), "se": ("k_se_gate",)}
+pat = {"conv": ("k_conv_f32", "k_conv_halo_f32", "k_conv1x1_f32_stream"), "dw": ("k_dwconv",), "pool": ("k_global_avgpool",), "se": ("k_se_gate",)}
 rows = [r for r in csv.DictReader(open(f)) if any(p in r["Kernel_Name"] for ps in pat.values() for p in ps)]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a convolution layer may be two launches (whole rounds + half-tile remainder); gated convolutions never split

@@ -50,7 +50,7 @@ for li, (planes, nb, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2),
 # (the projection head is no longer a k_conv_f32 launch: k_pool_linear_l2norm, reported below)
 import os
 f = max(glob.glob("gpurun_out/prof_enc/*/*kernel_trace.csv"), key=os.path.getmtime)
-rows = [r for r in csv.DictReader(open(f)) if "k_conv_f32" in r["Kernel_Name"] or "k_conv1x1_f32_stream" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "k_conv_f32" in r["Kernel_Name"] or "k_conv_halo_f32" in r["Kernel_Name"] or "k_conv1x1_f32_stream" in r["Kernel_Name"]]
 need = [1 if "shortcut" in name else conv_launches(m, k, nn) for (name, m, k, nn, ib, ob, rb) in layers]
 last = rows[-sum(need):]
 merged, pos = [], 0
@@ -70,7 +70,7 @@ for (name, m, k, nn, ib, ob, rb), r in zip(layers, last):
     fl = 2.0 * m * k * nn
     tot_t += us; tot_f += fl
     kn = r["Kernel_Name"]
-    tile = "ring 128, 256" if "ring" in kn else ("stream " if "stream" in kn else "") + kn.split("<")[1].split(">")[0]
+    tile = "ring 128, 256" if "ring" in kn else ("halo MI=" if "halo" in kn else "stream " if "stream" in kn else "") + kn.split("<")[1].split(">")[0]
     print(f"{name:22s} {m:9d} {k:5d} {nn:5d} {us:8.1f} {fl/us/1e6:8.1f} {fl/us/1e6/157.3:7.2f} {(ib+ob+rb)/us/1e3:7.0f}  {tile}")
     kind = name.split(".")[-1].split(" ")[0] if name.startswith("l") else name.split(" ")[0]
     a = agg.setdefault(name[:2] + " " + kind, [0, 0]); a[0] += us; a[1] += fl

@@ -151,7 +151,9 @@ def test_conv1x1_silu_and_residual_after_activation(device: torch.device) -> Non
     assert _rel_err(got, base + res) < 1e-5
 
 
-@pytest.mark.parametrize("b,h,w,cout,k,stride,pad", [(2, 37, 29, 64, 7, 2, 3), (1, 16, 16, 128, 3, 1, 1), (3, 9, 20, 64, 5, 2, 2)])
+@pytest.mark.parametrize("b,h,w,cout,k,stride,pad", [(2, 37, 29, 64, 7, 2, 3), (1, 16, 16, 128, 3, 1, 1), (3, 9, 20, 64, 5, 2, 2),
+                                                      (4, 224, 224, 64, 7, 2, 3),  # ResNet-50's stem at its own size (halo-tile kernel)
+                                                      (4, 224, 224, 24, 3, 2, 1)])  # EfficientNetV2's stem
 def test_conv2d_stem_mode(b, h, w, cout, k, stride, pad, device: torch.device) -> None:
     """Cin == 4 (RGB + zero channel), the packed-K mode with eight filter taps per K step; weights [Cout, ceil(k*k/8)*8, 4]."""
     from imagescry_amd import _lib
@@ -191,6 +193,14 @@ def test_conv2d_stem_mode(b, h, w, cout, k, stride, pad, device: torch.device) -
         (4, 1, 1, 40, 960, 1, 1, 0),  # squeeze-excitation fc2 from an unpadded squeeze width
         (8, 150, 150, 24, 24, 3, 1, 1),  # packed-K over more tiles than resident workgroups (32 x 256 tiles)
         (8, 150, 150, 8, 48, 3, 2, 1),  # ... 64 x 256 tiles would need Cout > 32: 48 -> 64 x 256, stride 2
+        # the halo-tile kernel (conv_halo.hip: Cin <= 24, Cout <= 64, square odd filter, "same" padding): image smaller than
+        # one 16 x 16 tile, ragged tiles in both directions, 5 x 5 and 7 x 7 windows, stride 2 on odd sizes, 1 - 6 chunks per
+        # pixel, Cout of one / two / three / four 16-channel blocks, more tiles than resident workgroups
+        (1, 5, 7, 24, 24, 3, 1, 1),
+        (3, 33, 47, 12, 40, 5, 1, 2),
+        (2, 45, 31, 20, 64, 7, 2, 3),
+        (2, 64, 64, 16, 4, 3, 2, 1),
+        (5, 200, 208, 24, 24, 3, 1, 1),
     ],
 )
 @pytest.mark.parametrize("epilogue", ["bias_silu", "bias_silu_then_res"])
