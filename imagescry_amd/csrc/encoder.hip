@@ -107,7 +107,7 @@ __device__ __forceinline__ void conv_dma16(const void* gsrc, unsigned char* lds_
 // DUAL = the instantiation that knows the K-concatenated second input (ConvParams::x2); a kernel of its own so that the
 // plain ones keep their register allocation (with the branch in every instantiation the 64 x 256 tile spilled 35 registers).
 template <int TCO, int TPIX, bool TAP4, bool DMA, bool DUAL = false>
-__global__ __launch_bounds__(256, 2) void k_conv_f32(const ConvParams p, int ntiles) {
+__global__ __launch_bounds__(256, (TCO * TPIX <= 8192 && !TAP4 ? 3 : 2)) void k_conv_f32(const ConvParams p, int ntiles) {
     static_assert(!DUAL || (DMA && !TAP4), "the second input exists in the LDS-DMA form without packed-K only");
     constexpr int WCO = TCO >= 64 ? TCO / 64 : 1;  // waves along the output channels
     constexpr int MI = TCO / WCO / 16;             // 16-channel blocks per wave: 4, or 2 for the 32-channel tile
@@ -1046,6 +1046,16 @@ static bool conv_no_split() {
 static constexpr bool conv_no_split() { return false; }
 #endif
 
+// Layers of at most this many K steps run as HALF tiles throughout (three workgroups per CU instead of two), see conv_launch
+#ifdef ISC_ABLATION
+static int conv_halves_ksteps() {
+    static const int v = getenv("ISC_CONV_HALVES_KSTEPS") ? atoi(getenv("ISC_CONV_HALVES_KSTEPS")) : 8;
+    return v;
+}
+#else
+static constexpr int conv_halves_ksteps() { return 8; }
+#endif
+
 // conv_halo.hip: small-channel R x R layers with the pixel operand gathered from an input halo tile in LDS
 bool isc_conv_halo_applies(int Cin, int Cout, int R, int S, int stride, int pad, bool has_sub_or_scale, size_t* lds_bytes);
 int isc_conv_halo_launch(const float* x, int B, int H, int W, int Cin, const float* w, int Cout, int R, int S, int stride,
@@ -1135,6 +1145,21 @@ static int conv_launch(const float* x, int B, int H, int W, int Cin, const float
     // tiles on 512): whole rounds as one perfectly balanced launch, the remainder as HALF tiles (128 x 64, 64 x 128) in a
     // second one -- its round then costs half a tile time, or spreads over twice the CUs, instead of a whole one.  Worth a
     // second launch only when a tile is long (>= 16 K steps) or there is no whole round at all.
+    // Short-K layers (K <= 256: the 1 x 1 expand / project convolutions) are bound by their tiles' prologue and epilogue,
+    // not by the matrix pipe: as half tiles (128 x 64, 64 x 128; 48 KiB of LDS, 168 registers) THREE workgroups fit a CU
+    // and a third independent stream covers the other two's residual reads and stores.  Same-device A/B of the step
+    // (gpurun_out/r4/ab_halves_*.log): EfficientNetV2-S 35.92 -> 35.74 ms, ResNet-50 39.89 -> 39.79 ms.
+    if (dma && !tile32 && !tap4 && !conv_one_tile_per_wg() && ksteps <= conv_halves_ksteps() && 2 * blocks <= 0x7fffffff) {
+        ConvParams q = p;
+        q.tile_split = 2;
+        const int halves = (int)(2 * blocks);
+        const int64_t res3 = 3 * (int64_t)conv_cu_count();
+        const dim3 g((unsigned)(halves > res3 ? res3 : halves));
+        if (narrow) hipLaunchKernelGGL((k_conv_f32<64, 128, false, true>), g, block, 0, s, q, halves);
+        else hipLaunchKernelGGL((k_conv_f32<128, 64, false, true>), g, block, 0, s, q, halves);
+        isc_timing_end(ISC_KERNEL_CONV, s);
+        return isc_launch_status();
+    }
     if (dma && !tile32 && !conv_one_tile_per_wg() && !conv_no_split()) {
         const int64_t rounds = blocks / resident, rem = blocks - rounds * resident;
         if (rem > 0 && rem * 4 <= resident * 3 && (ksteps >= 16 || rounds == 0)) {
