@@ -506,6 +506,10 @@ int isc_gemm_f16_stream_launch(const void* a, long long M, int K, const void* w,
     const int fbs = N / GT;
     // groups of 4 (or 3) feature blocks share an XCD's L2; 32 CUs per XCD
     p.group = fbs % 4 == 0 ? 4 : fbs % 3 == 0 ? 3 : fbs % 2 == 0 ? 2 : 1;
+#ifdef ISC_ABLATION
+    static const int force_group = getenv("ISC_GEMM_GROUP") ? atoi(getenv("ISC_GEMM_GROUP")) : 0;  // A/B aid
+    if (force_group > 0 && fbs % force_group == 0) p.group = force_group;
+#endif
     p.ngroups = fbs / p.group;
     const int pairs_per_xcd = 32 / p.group;
     int want = 8 * pairs_per_xcd / p.ngroups;  // chunks of token tiles
