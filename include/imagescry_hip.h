@@ -69,7 +69,7 @@ int isc_device_info(int* num_cus, int* lds_bytes_per_cu, char* arch_name, int ar
  * trace counts in: a convolution that runs as whole rounds + a half-tile remainder counts two), and clears them (host
  * pointers). */
 #define ISC_KERNEL_DOTS_FILTER 0 /* k_dots_filter: the MFMA score + threshold-filter pass of isc_cosine_topk */
-#define ISC_KERNEL_CONV 1        /* k_conv_f32: the implicit-GEMM convolution of isc_conv2d_nhwc */
+#define ISC_KERNEL_CONV 1        /* k_conv_f32 / k_conv_halo_f32: the implicit-GEMM convolutions of isc_conv2d_nhwc */
 #define ISC_KERNEL_GEMM_F16 2    /* k_gemm_f16: the fp16 GEMM of isc_gemm_f16 (transformer encoder) */
 #define ISC_KERNEL_COUNT 3
 int isc_timing_enable(int enable);
