@@ -107,7 +107,7 @@ __device__ __forceinline__ void conv_dma16(const void* gsrc, unsigned char* lds_
 // DUAL = the instantiation that knows the K-concatenated second input (ConvParams::x2); a kernel of its own so that the
 // plain ones keep their register allocation (with the branch in every instantiation the 64 x 256 tile spilled 35 registers).
 template <int TCO, int TPIX, bool TAP4, bool DMA, bool DUAL = false>
-__global__ __launch_bounds__(256, (TCO * TPIX <= 8192 && !TAP4 ? 3 : 2)) void k_conv_f32(const ConvParams p, int ntiles) {
+__global__ __launch_bounds__(256, (TCO * TPIX <= 8192 && TCO >= 64 && !TAP4 ? 3 : 2)) void k_conv_f32(const ConvParams p, int ntiles) {
     static_assert(!DUAL || (DMA && !TAP4), "the second input exists in the LDS-DMA form without packed-K only");
     constexpr int WCO = TCO >= 64 ? TCO / 64 : 1;  // waves along the output channels
     constexpr int MI = TCO / WCO / 16;             // 16-channel blocks per wave: 4, or 2 for the 32-channel tile

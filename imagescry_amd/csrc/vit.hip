@@ -587,6 +587,113 @@ typedef short tr8 __attribute__((__vector_size__(8 * sizeof(short))));
 // loop -- feeding v_exp_f32 directly, instead of a subtraction, a multiplication and the exponential; the masks shrink
 // from two instructions per score to two per score of ONE block.  Per 16-query block: ~230 vector instructions instead
 // of ~390 (28 K-fragment reads, 26 + 28 MFMAs).
+// One block of 16 queries against the staged keys / values of a head: scores, softmax, P V, output row.  qf = this lane's two
+// query fragments, already scaled by 1/8; orow = where query tq's 64 outputs go (tq < T), qi / g = lane & 15 / lane >> 4.
+template <int NKB, bool TAIL>
+__device__ __forceinline__ void att_query_block(const _Float16* __restrict__ Ks, const _Float16* __restrict__ Vs,
+                                                const half8 (&qf)[2], int T, int tq, int qi, int g,
+                                                _Float16* __restrict__ orow) {
+    constexpr float LOG2E = 1.4426950408889634f;
+    f32x4 s[NKB];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const half8 kf = *reinterpret_cast<const half8*>(&Ks[(kb * 16 + qi) * ATT_KSTRIDE + (kk * 4 + g) * 8]);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], a, 0, 0, 0);
+        }
+        if (!TAIL || kb == NKB - 1) {  // (compile-time) the block(s) that can hold keys past T
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (kb * 16 + g * 4 + r >= T) a[r] = -INFINITY;
+        }
+        s[kb] = a;
+        __builtin_amdgcn_sched_barrier(0);  // keep the fragment loads of later key blocks from piling up in VGPRs
+    }
+    // The row maximum, v_max3_f32 by hand: through fmaxf the compiler first canonicalises every matrix-core result (one
+    // v_max_f32 x, x each -- 52 more instructions per query block than the 26 maxima themselves).  hipcc pads no
+    // hazards for an asm statement (cdna_hip_programming.md 5.7), and a vector instruction that reads a register a
+    // matrix-core instruction has just written needs its wait states: so the maxima run in ONE block behind the whole
+    // score loop, fenced from it by a scheduling barrier, and the block opens with those wait states itself (12 >= the 11
+    // an 8-pass MFMA result needs; the last MFMA's result is read by the mask code in between at the earliest).
+    __builtin_amdgcn_sched_barrier(0);
+    // six score blocks (twelve v_max3_f32) per statement: 25 register operands, under the limit of 30
+#define ISC_ATT_MAX6(k_, PRE_)                                                                                         \
+asm volatile(PRE_ "v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\t"         \
+             "v_max3_f32 %0, %0, %7, %8\n\tv_max3_f32 %0, %0, %9, %10\n\tv_max3_f32 %0, %0, %11, %12\n\t"           \
+             "v_max3_f32 %0, %0, %13, %14\n\tv_max3_f32 %0, %0, %15, %16\n\tv_max3_f32 %0, %0, %17, %18\n\t"        \
+             "v_max3_f32 %0, %0, %19, %20\n\tv_max3_f32 %0, %0, %21, %22\n\tv_max3_f32 %0, %0, %23, %24"             \
+             : "+v"(mx)                                                                                            \
+             : "v"(s[k_][0]), "v"(s[k_][1]), "v"(s[k_][2]), "v"(s[k_][3]), "v"(s[k_ + 1][0]), "v"(s[k_ + 1][1]),   \
+               "v"(s[k_ + 1][2]), "v"(s[k_ + 1][3]), "v"(s[k_ + 2][0]), "v"(s[k_ + 2][1]), "v"(s[k_ + 2][2]),      \
+               "v"(s[k_ + 2][3]), "v"(s[k_ + 3][0]), "v"(s[k_ + 3][1]), "v"(s[k_ + 3][2]), "v"(s[k_ + 3][3]),      \
+               "v"(s[k_ + 4][0]), "v"(s[k_ + 4][1]), "v"(s[k_ + 4][2]), "v"(s[k_ + 4][3]), "v"(s[k_ + 5][0]),      \
+               "v"(s[k_ + 5][1]), "v"(s[k_ + 5][2]), "v"(s[k_ + 5][3]))
+#define ISC_ATT_MAX1(k_)                                                                  \
+asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4"                  \
+             : "+v"(mx)                                                               \
+             : "v"(s[k_][0]), "v"(s[k_][1]), "v"(s[k_][2]), "v"(s[k_][3]))
+    static_assert(NKB == 13 || NKB == 14, "the maxima are written out for thirteen or fourteen key blocks");
+    ISC_ATT_MAX6(0, "s_nop 7\n\ts_nop 3\n\t");  // the wait states of the matrix-core results, inside the statement
+    ISC_ATT_MAX6(6, "");
+    ISC_ATT_MAX1(12);
+    if constexpr (NKB == 14) ISC_ATT_MAX1(NKB - 1);
+#undef ISC_ATT_MAX6
+#undef ISC_ATT_MAX1
+    __builtin_amdgcn_sched_barrier(0);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxl = -mx * LOG2E;  // T >= 1: every query has a finite maximum
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, mxl));  // masked keys: exp2(-inf) = 0
+            s[kb][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+
+    f32x4 o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < (NKB + 1) / 2; ++ks) {
+        half8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pf[r] = (_Float16)s[2 * ks][r];
+            pf[4 + r] = 2 * ks + 1 < NKB ? (_Float16)s[2 * ks + 1 < NKB ? 2 * ks + 1 : 0][r] : (_Float16)0.f;
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            // V^T fragment: slot j of lane group g is key 32 ks + 4 g + j (j < 4) / 32 ks + 16 + 4 g + (j - 4), of value
+            // column 16 db + qi.  One transposed read hands every lane of a 16-lane group ITS column of a 4-row block;
+            // lane 4 q + p of the group supplies the address of row q, columns 4 p .. 4 p + 3 (EXEC is all ones here).
+            const _Float16* vb = &Vs[(ks * 32 + g * 4 + (qi >> 2)) * ATT_VSTRIDE + db * 16 + (qi & 3) * 4];
+            const tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)vb);
+            const tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)(vb + 16 * ATT_VSTRIDE));
+            const half8 vf = __builtin_bit_cast(half8, tr8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[db], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tq < T) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            half4 hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = (_Float16)(o[db][r] * inv);
+            *reinterpret_cast<half4*>(orow + db * 16 + g * 4) = hv;
+        }
+    }
+}
+
 #ifdef ISC_ABLATION
 __device__ int g_att_abl = 0;  // ISC_ATT_ABL (timing aid, wrong results): 1 = stage keys / values only, 2 = no staging loads
 #endif
@@ -764,6 +871,99 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
     }
 }
 
+// The PERSISTENT form (round 4): one workgroup of SIXTEEN waves per CU walks the (image, head) pairs blockIdx.x,
+// + gridDim.x, ...  A head's thirteen (fourteen) query blocks run as ONE round, a wave each, and the keys / values of
+// the NEXT head are requested into registers before that round starts and written into the other LDS image after it --
+// in k_attention_f16 a workgroup loads, then computes, and the second workgroup of the CU does not fill the gap: the
+// two phases add up (staging alone 49 us of a 178 us layer).  Same staging layout, same query-block
+// arithmetic (att_query_block), bit-identical results.
+constexpr int ATT_P_THREADS = 1024;
+constexpr int ATT_P_LDS_BYTES = 2 * ATT_TMAX * (ATT_KSTRIDE + ATT_VSTRIDE) * 2;  // two (K, V) images: 126 KiB
+template <bool PACKED, int NKB, bool TAIL>
+__global__ __launch_bounds__(ATT_P_THREADS) void k_attention_f16_p(const _Float16* __restrict__ qkv, int T, int heads,
+                                                                    _Float16* __restrict__ out, int total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char att_lds[];
+    constexpr int IMG = ATT_TMAX * (ATT_KSTRIDE + ATT_VSTRIDE);  // halves per (K, V) image
+    _Float16* const kv = reinterpret_cast<_Float16*>(att_lds);
+    const int D = heads * 64;
+    const size_t row_stride = (size_t)3 * D;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int qi = lane & 15;
+    const int g = lane >> 4;
+    const int nqb = (T + 15) >> 4;  // <= 14 waves have a query block
+    const int tq = wave * 16 + qi;
+    auto qkv_at = [&](int b, int h, int t, int part, int c) -> const _Float16* {
+        if (PACKED) return qkv + pk_offset((long long)b * T + t, part * D + h * 64, 3 * D) + c * 8;
+        return qkv + ((size_t)b * T + t) * row_stride + part * D + h * 64 + c * 8;
+    };
+    constexpr int TROWS = NKB * 16 < ATT_TMAX ? (NKB + (NKB & 1)) * 16 : ATT_TMAX;
+    constexpr int SROUNDS = (TROWS * 8 + ATT_P_THREADS - 1) / ATT_P_THREADS;
+    half8 kreg[SROUNDS], vreg[SROUNDS], qn[2];
+    auto load_item = [&](int item) {
+        const int b = item / heads, h = item - b * heads;
+#pragma unroll
+        for (int r = 0; r < SROUNDS; ++r) {
+            const int i = tid + r * ATT_P_THREADS;
+            const int t = i >> 3, c = i & 7;
+            kreg[r] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            vreg[r] = kreg[r];
+            if (t < T) {
+                kreg[r] = *reinterpret_cast<const half8*>(qkv_at(b, h, t, 1, c));
+                vreg[r] = *reinterpret_cast<const half8*>(qkv_at(b, h, t, 2, c));
+            }
+        }
+        if (wave < nqb) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) qn[kk] = *reinterpret_cast<const half8*>(qkv_at(b, h, min(tq, T - 1), 0, kk * 4 + g));
+        }
+    };
+    auto store_item = [&](int buf) {
+        _Float16* Ks = kv + buf * IMG;
+        _Float16* Vs = Ks + ATT_TMAX * ATT_KSTRIDE;
+#pragma unroll
+        for (int r = 0; r < SROUNDS; ++r) {
+            const int i = tid + r * ATT_P_THREADS;
+            const int t = i >> 3, c = i & 7;
+            if (i < TROWS * 8) {
+                *reinterpret_cast<half8*>(&Ks[t * ATT_KSTRIDE + c * 8]) = kreg[r];
+                *reinterpret_cast<half8*>(&Vs[t * ATT_VSTRIDE + c * 8]) = vreg[r];
+            }
+        }
+    };
+    int item = blockIdx.x;
+    if (item >= total) return;
+    load_item(item);
+    store_item(0);
+    half8 qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[kk][j] = qn[kk][j] * (_Float16)0.125f;  // 1/sqrt(64): exact scaling
+    __syncthreads();
+    for (int it = 0;; ++it) {
+        const int next = item + (int)gridDim.x;
+        const bool more = next < total;
+        if (more) load_item(next);  // in flight under this head's round
+        if (wave < nqb) {
+            const int b = item / heads, h = item - b * heads;
+            const _Float16* Ks = kv + (it & 1) * IMG;
+            _Float16* orow = PACKED ? out + pk_offset((long long)b * T + min(tq, T - 1), h * 64, D)
+                                    : out + ((size_t)b * T + min(tq, T - 1)) * D + h * 64;
+            att_query_block<NKB, TAIL>(Ks, Ks + ATT_TMAX * ATT_KSTRIDE, qf, T, tq, qi, g, orow);
+        }
+        if (!more) break;
+        store_item((it + 1) & 1);  // the image the PREVIOUS head was read from: every wave is past that round's barrier
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[kk][j] = qn[kk][j] * (_Float16)0.125f;
+        __syncthreads();
+        item = next;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // patches[b * gh * gw + (ph * gw + pw)][c * P * P + r * P + s] = fp16(x[b][c][ph * P + r][pw * P + s]); 8 values a thread
 __global__ __launch_bounds__(256) void k_patchify_f16(const float* __restrict__ x, int C, int H, int W, int P,
@@ -926,6 +1126,20 @@ extern "C" int isc_layernorm(const float* x, int64_t rows, int D, int64_t ldx, c
     return isc_launch_status();
 }
 
+// the 126 KiB of dynamic LDS k_attention_f16_p asks for have to be allowed once per (instantiation, device)
+static bool att_p_prepare(const void* fn, unsigned long long* done) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && ((__atomic_load_n(done, __ATOMIC_RELAXED) >> dev) & 1ull)) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_P_LDS_BYTES) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (tracked) __atomic_fetch_or(done, 1ull << dev, __ATOMIC_RELAXED);
+    return true;
+}
+
 extern "C" int isc_attention_f16(const void* qkv, int B, int T, int heads, int head_dim, void* out, int packed,
                                  void* stream) {
     ISC_REQUIRE(qkv && out && B > 0 && T > 0 && heads > 0);
@@ -939,10 +1153,30 @@ extern "C" int isc_attention_f16(const void* qkv, int B, int T, int heads, int h
     }();
     (void)att_abl_set;
 #endif
+    // the persistent sixteen-wave form wherever there is more than one head per CU to walk (k_attention_f16_p)
+    const int total = B * heads;
+    const int cus = isc_device_cus();
+#ifdef ISC_ABLATION
+    static const bool one_shot = getenv("ISC_ATT_ONE_SHOT") != nullptr;  // A/B aid: one workgroup per head, as before
+#else
+    constexpr bool one_shot = false;
+#endif
+    const bool persistent = !one_shot && total > cus;
 #define ISC_ATT_LAUNCH(PK_, NKB_, TAIL_)                                                                              \
-    hipLaunchKernelGGL((k_attention_f16<PK_, NKB_, TAIL_>), dim3((unsigned)(B * heads)), dim3(ATT_THREADS), 0,          \
-                       isc_stream(stream), reinterpret_cast<const _Float16*>(qkv), T, heads,                            \
-                       reinterpret_cast<_Float16*>(out))
+    do {                                                                                                              \
+        if (persistent) {                                                                                             \
+            auto kern = k_attention_f16_p<PK_, NKB_, TAIL_>;                                                          \
+            static unsigned long long attr_done = 0; /* per device: the dynamic-LDS limit of this instantiation is set */ \
+            if (!att_p_prepare(reinterpret_cast<const void*>(kern), &attr_done)) return ISC_ERR_UNSUPPORTED;          \
+            hipLaunchKernelGGL(kern, dim3((unsigned)cus), dim3(ATT_P_THREADS), ATT_P_LDS_BYTES, isc_stream(stream),   \
+                               reinterpret_cast<const _Float16*>(qkv), T, heads, reinterpret_cast<_Float16*>(out),    \
+                               total);                                                                                \
+        } else {                                                                                                      \
+            hipLaunchKernelGGL((k_attention_f16<PK_, NKB_, TAIL_>), dim3((unsigned)total), dim3(ATT_THREADS), 0,      \
+                               isc_stream(stream), reinterpret_cast<const _Float16*>(qkv), T, heads,                  \
+                               reinterpret_cast<_Float16*>(out));                                                     \
+        }                                                                                                             \
+    } while (0)
     // 192 < T <= 208 (ViT-B/16: 197 tokens): thirteen key blocks, only the last one masked; 208 < T: fourteen, likewise;
     // anything shorter: the generic form (fourteen blocks, every element masked)
     if (T > 208) {

@@ -190,6 +190,10 @@ def f_gemm():
 
 def f_attention():
     b, t, heads = int(rng.integers(1, 4)), int(rng.choice([1, 2, 15, 16, 17, 50, 191, 192, 193, 197, 207, 208, 209, 223, 224])), int(rng.integers(1, 5))
+    if rng.random() < 0.3:  # more (image, head) pairs than CUs: the persistent sixteen-wave form, one to three heads per workgroup
+        heads = int(rng.choice([1, 3, 12]))
+        b = int(rng.integers(257, 700)) // heads + 1
+        t = int(rng.choice([1, 16, 17, 50, 193, 197, 208, 209, 224]))
     pk = bool(rng.random() < 0.5)
     d = heads * 64
     g = gen()

@@ -171,6 +171,36 @@ def test_attention(device, b, t, heads, pk):
     torch.testing.assert_close(out.double().cpu(), want, rtol=4e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("pk", [False, True])
+@pytest.mark.parametrize("b,t,heads", [(30, 197, 12), (43, 17, 7), (23, 209, 12), (600, 5, 1), (260, 33, 1)])
+def test_attention_more_heads_than_cus(device, b, t, heads, pk):
+    """b * heads > 256: the persistent form (k_attention_f16_p: one 16-wave workgroup per CU walks the (image, head) pairs, the
+    next pair's keys / values prefetched under the current round).  Against the float64 softmax AND, bit for bit, against the
+    one-workgroup-per-head kernel run on slices of at most 256 pairs."""
+    from imagescry_amd import _lib
+    from imagescry_amd.vit import pack_rows, packed_elems, unpack_rows
+
+    d = heads * 64
+    g = _gen(b * t + heads + 5)
+    qkv = (torch.randn(b, t, 3 * d, generator=g) * 1.5).half()
+    q, k, v = (z.reshape(b, t, heads, 64).transpose(1, 2).double() for z in qkv.split(d, dim=-1))
+    want = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).transpose(1, 2).reshape(b, t, d)
+    lib = _lib.load()
+
+    def run(x: torch.Tensor) -> torch.Tensor:
+        n = x.shape[0]
+        xd = (pack_rows(x.reshape(n * t, 3 * d)) if pk else x).to(device)
+        out = torch.full((packed_elems(n * t, d) if pk else n * t * d,), float("nan"), dtype=torch.float16, device=device)
+        _lib.check(lib.isc_attention_f16(xd.data_ptr(), n, t, heads, 64, out.data_ptr(), int(pk), _lib.stream_handle(device)), "att")
+        return (unpack_rows(out, n * t, d) if pk else out).view(n, t, d).cpu()
+
+    got = run(qkv)
+    torch.testing.assert_close(got.double(), want, rtol=4e-3, atol=2e-3)
+    step = max(1, 256 // heads)  # at most 256 pairs per call: the one-shot kernel
+    sliced = torch.cat([run(qkv[i : i + step]) for i in range(0, b, step)])
+    assert torch.equal(got, sliced)
+
+
 def test_attention_limits(device):
     from imagescry_amd import _lib
 
