@@ -280,6 +280,27 @@ def test_im2col_maxpool_avgpool(device: torch.device) -> None:
     assert float(z[..., 3:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize(
+    "b,h,w,c,r,stride,pad",
+    [(3, 112, 112, 64, 3, 2, 1), (2, 2, 2, 8, 3, 2, 1), (1, 3, 5, 4, 3, 2, 1), (2, 7, 64, 12, 3, 2, 1), (1, 1, 9, 4, 3, 2, 1),
+     (2, 10, 11, 8, 2, 2, 0), (1, 9, 9, 16, 3, 1, 1), (1, 12, 7, 4, 5, 2, 2)],
+)
+def test_maxpool_shapes(b, h, w, c, r, stride, pad, device: torch.device) -> None:
+    """Bit-exact against F.max_pool2d, -inf rows included (ResNet-50's 3 x 3 / 2 / 1 at its own size, degenerate images,
+    other windows)."""
+    from imagescry_amd import _lib
+
+    g = cases.gen(b * h + w + c)
+    x = torch.randn(b, c, h, w, generator=g)
+    x[0, :, 0, :] = float("-inf")
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device)
+    ho, wo = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - r) // stride + 1
+    out = torch.full((b, ho, wo, c), float("nan"), device=device)
+    _lib.check(_lib.load().isc_maxpool_nhwc(xd.data_ptr(), b, h, w, c, r, stride, pad, out.data_ptr(), _lib.stream_handle(device)),
+               "maxpool")
+    np.testing.assert_array_equal(out.permute(0, 3, 1, 2).cpu().numpy(), F.max_pool2d(x, r, stride, pad).numpy())
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 64, 64), (3, 3, 96, 80), (1, 3, 35, 42)])
 def test_resnet50_forward_matches_oracle(shape: tuple[int, ...], device: torch.device) -> None:
     from imagescry_amd import ResNet50Embedder, resnet50
