@@ -127,8 +127,13 @@ int first_ratio() {
     static const int v = getenv("ISC_FIRST_RATIO") ? atoi(getenv("ISC_FIRST_RATIO")) : 16;  // A/B aid; 1 << 20 = off
     return v;
 }
+int sample_tiles_cap() {
+    static const int v = getenv("ISC_SAMPLE_TILES") ? atoi(getenv("ISC_SAMPLE_TILES")) : 0;  // A/B aid: cap of the sample level's tiles
+    return v;
+}
 #else
 constexpr int first_ratio() { return 16; }
+constexpr int sample_tiles_cap() { return 0; }
 #endif
 
 Plan make_plan(int64_t n, int q, int k) {
@@ -161,6 +166,7 @@ Plan make_plan(int64_t n, int q, int k) {
     };
     int64_t stiles = p.nslots ? (int64_t)(QCAP * 7 / 10) / (p.kp * 27 / 20) : 16;
     if (stiles > wgs) stiles = wgs;
+    if (sample_tiles_cap() > 0 && stiles > sample_tiles_cap()) stiles = sample_tiles_cap();
     if (stiles < 1) stiles = 1;
     if (stiles > ntiles_all) stiles = ntiles_all;
     int64_t seen = stiles * TM < n ? stiles * TM : n;
