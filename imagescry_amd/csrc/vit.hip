@@ -694,137 +694,6 @@ asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4"           
     }
 }
 
-// TWO blocks of 16 queries in one wave (k_attention_f16_q2): every key fragment and every transposed value fragment is
-// read from LDS ONCE and feeds both blocks' MFMAs -- half the LDS traffic per query of att_query_block, whose waves each
-// read all of K and V for 16 queries (~700 KB per head and CU, ~45 % of the LDS bandwidth) -- and the two softmax chains are
-// independent, so one wave overlaps the latencies two waves used to.  Same arithmetic per query, bit-identical results.
-template <int NKB, bool TAIL>
-__device__ __forceinline__ void att_query_block2(const _Float16* __restrict__ Ks, const _Float16* __restrict__ Vs,
-                                                 const half8 (&qf)[2][2], int T, const int (&tq)[2], int qi, int g,
-                                                 _Float16* const (&orow)[2]) {
-    constexpr float LOG2E = 1.4426950408889634f;
-    f32x4 s0[NKB], s1[NKB];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const half8 kf = *reinterpret_cast<const half8*>(&Ks[(kb * 16 + qi) * ATT_KSTRIDE + (kk * 4 + g) * 8]);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][kk], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][kk], a1, 0, 0, 0);
-        }
-        if (!TAIL || kb == NKB - 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (kb * 16 + g * 4 + r >= T) {
-                    a0[r] = -INFINITY;
-                    a1[r] = -INFINITY;
-                }
-        }
-        s0[kb] = a0;
-        s1[kb] = a1;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // row maxima by v_max3_f32 (see att_query_block: the statements carry their own wait states behind the MFMAs)
-    float mx0 = -INFINITY, mx1 = -INFINITY;
-    __builtin_amdgcn_sched_barrier(0);
-#define ISC_ATT2_MAX6(S_, MX_, k_, PRE_)                                                                               \
-    asm volatile(PRE_ "v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\t"         \
-                 "v_max3_f32 %0, %0, %7, %8\n\tv_max3_f32 %0, %0, %9, %10\n\tv_max3_f32 %0, %0, %11, %12\n\t"           \
-                 "v_max3_f32 %0, %0, %13, %14\n\tv_max3_f32 %0, %0, %15, %16\n\tv_max3_f32 %0, %0, %17, %18\n\t"        \
-                 "v_max3_f32 %0, %0, %19, %20\n\tv_max3_f32 %0, %0, %21, %22\n\tv_max3_f32 %0, %0, %23, %24"             \
-                 : "+v"(MX_)                                                                                           \
-                 : "v"(S_[k_][0]), "v"(S_[k_][1]), "v"(S_[k_][2]), "v"(S_[k_][3]), "v"(S_[k_ + 1][0]), "v"(S_[k_ + 1][1]),   \
-                   "v"(S_[k_ + 1][2]), "v"(S_[k_ + 1][3]), "v"(S_[k_ + 2][0]), "v"(S_[k_ + 2][1]), "v"(S_[k_ + 2][2]),      \
-                   "v"(S_[k_ + 2][3]), "v"(S_[k_ + 3][0]), "v"(S_[k_ + 3][1]), "v"(S_[k_ + 3][2]), "v"(S_[k_ + 3][3]),      \
-                   "v"(S_[k_ + 4][0]), "v"(S_[k_ + 4][1]), "v"(S_[k_ + 4][2]), "v"(S_[k_ + 4][3]), "v"(S_[k_ + 5][0]),      \
-                   "v"(S_[k_ + 5][1]), "v"(S_[k_ + 5][2]), "v"(S_[k_ + 5][3]))
-#define ISC_ATT2_MAX1(S_, MX_, k_)                                                        \
-    asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4"                  \
-                 : "+v"(MX_)                                                              \
-                 : "v"(S_[k_][0]), "v"(S_[k_][1]), "v"(S_[k_][2]), "v"(S_[k_][3]))
-    static_assert(NKB == 13 || NKB == 14, "the maxima are written out for thirteen or fourteen key blocks");
-    ISC_ATT2_MAX6(s0, mx0, 0, "s_nop 7\n\ts_nop 3\n\t");
-    ISC_ATT2_MAX6(s0, mx0, 6, "");
-    ISC_ATT2_MAX1(s0, mx0, 12);
-    if constexpr (NKB == 14) ISC_ATT2_MAX1(s0, mx0, NKB - 1);
-    ISC_ATT2_MAX6(s1, mx1, 0, "");
-    ISC_ATT2_MAX6(s1, mx1, 6, "");
-    ISC_ATT2_MAX1(s1, mx1, 12);
-    if constexpr (NKB == 14) ISC_ATT2_MAX1(s1, mx1, NKB - 1);
-#undef ISC_ATT2_MAX6
-#undef ISC_ATT2_MAX1
-    __builtin_amdgcn_sched_barrier(0);
-    mx0 = fmaxf(mx0, __shfl_xor(mx0, 16, 64));
-    mx1 = fmaxf(mx1, __shfl_xor(mx1, 16, 64));
-    mx0 = fmaxf(mx0, __shfl_xor(mx0, 32, 64));
-    mx1 = fmaxf(mx1, __shfl_xor(mx1, 32, 64));
-    const float mxl0 = -mx0 * LOG2E, mxl1 = -mx1 * LOG2E;
-    float sum0 = 0.f, sum1 = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float e0 = __builtin_amdgcn_exp2f(fmaf(s0[kb][r], LOG2E, mxl0));
-            const float e1 = __builtin_amdgcn_exp2f(fmaf(s1[kb][r], LOG2E, mxl1));
-            s0[kb][r] = e0;
-            s1[kb][r] = e1;
-            sum0 += e0;
-            sum1 += e1;
-        }
-    sum0 += __shfl_xor(sum0, 16, 64);
-    sum1 += __shfl_xor(sum1, 16, 64);
-    sum0 += __shfl_xor(sum0, 32, 64);
-    sum1 += __shfl_xor(sum1, 32, 64);
-    const float inv0 = 1.f / sum0, inv1 = 1.f / sum1;
-
-    f32x4 o0[4], o1[4];
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-        o0[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-        o1[db] = o0[db];
-    }
-#pragma unroll
-    for (int ks = 0; ks < (NKB + 1) / 2; ++ks) {
-        half8 pf0, pf1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pf0[r] = (_Float16)s0[2 * ks][r];
-            pf1[r] = (_Float16)s1[2 * ks][r];
-            pf0[4 + r] = 2 * ks + 1 < NKB ? (_Float16)s0[2 * ks + 1 < NKB ? 2 * ks + 1 : 0][r] : (_Float16)0.f;
-            pf1[4 + r] = 2 * ks + 1 < NKB ? (_Float16)s1[2 * ks + 1 < NKB ? 2 * ks + 1 : 0][r] : (_Float16)0.f;
-        }
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            const _Float16* vb = &Vs[(ks * 32 + g * 4 + (qi >> 2)) * ATT_VSTRIDE + db * 16 + (qi & 3) * 4];
-            const tr4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)vb);
-            const tr4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)(vb + 16 * ATT_VSTRIDE));
-            const half8 vf = __builtin_bit_cast(half8, tr8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
-            o0[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf0, o0[db], 0, 0, 0);
-            o1[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf1, o1[db], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (tq[0] < T) {
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            half4 hv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hv[r] = (_Float16)(o0[db][r] * inv0);
-            *reinterpret_cast<half4*>(orow[0] + db * 16 + g * 4) = hv;
-        }
-    }
-    if (tq[1] < T) {
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            half4 hv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hv[r] = (_Float16)(o1[db][r] * inv1);
-            *reinterpret_cast<half4*>(orow[1] + db * 16 + g * 4) = hv;
-        }
-    }
-}
-
 #ifdef ISC_ABLATION
 __device__ int g_att_abl = 0;  // ISC_ATT_ABL (timing aid, wrong results): 1 = stage keys / values only, 2 = no staging loads
 #endif
@@ -1002,18 +871,17 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention_f16(const _Float16* _
     }
 }
 
-// The PERSISTENT form (round 4): one workgroup of EIGHT waves per CU walks the (image, head) pairs blockIdx.x,
-// + gridDim.x, ...  Waves 0 - 6 take two query blocks each (att_query_block2: every key / value fragment read from LDS once
-// for 32 queries, two independent softmax chains per wave), so a head's thirteen or fourteen blocks run as ONE round; the
-// keys, values and query fragments of the NEXT head are requested into registers before the round starts and written into
-// the other of two LDS images after it -- in k_attention_f16 a workgroup loads, then computes, and the second workgroup of
-// the CU does not fill the gap: the two phases add up (staging alone 49 us of a 178 us layer).  Same staging
-// layout, same arithmetic per query, bit-identical results.
-constexpr int ATT_P_THREADS = 512;
+// The PERSISTENT form (round 4): one workgroup of SIXTEEN waves per CU walks the (image, head) pairs blockIdx.x,
+// + gridDim.x, ...  A head's thirteen (fourteen) query blocks run as ONE round, a wave each, and the keys / values of
+// the NEXT head are requested into registers before that round starts and written into the other LDS image after it --
+// in k_attention_f16 a workgroup loads, then computes, and the second workgroup of the CU does not fill the gap: the
+// two phases add up (staging alone 49 us of a 178 us layer).  Same staging layout, same query-block
+// arithmetic (att_query_block), bit-identical results.
+constexpr int ATT_P_THREADS = 1024;
 constexpr int ATT_P_LDS_BYTES = 2 * ATT_TMAX * (ATT_KSTRIDE + ATT_VSTRIDE) * 2;  // two (K, V) images: 126 KiB
 template <bool PACKED, int NKB, bool TAIL>
-__global__ __launch_bounds__(ATT_P_THREADS, 2) void k_attention_f16_p(const _Float16* __restrict__ qkv, int T, int heads,
-                                                                       _Float16* __restrict__ out, int total) {
+__global__ __launch_bounds__(ATT_P_THREADS) void k_attention_f16_p(const _Float16* __restrict__ qkv, int T, int heads,
+                                                                    _Float16* __restrict__ out, int total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char att_lds[];
     constexpr int IMG = ATT_TMAX * (ATT_KSTRIDE + ATT_VSTRIDE);  // halves per (K, V) image
     _Float16* const kv = reinterpret_cast<_Float16*>(att_lds);
@@ -1024,16 +892,15 @@ __global__ __launch_bounds__(ATT_P_THREADS, 2) void k_attention_f16_p(const _Flo
     const int wave = tid >> 6;
     const int qi = lane & 15;
     const int g = lane >> 4;
-    const int nqb = (T + 15) >> 4;       // <= 14 query blocks: waves 0 .. 6 take two each
-    const bool active = 2 * wave < nqb;  // wave-uniform
-    const int tq[2] = {(2 * wave) * 16 + qi, (2 * wave + 1) * 16 + qi};
+    const int nqb = (T + 15) >> 4;  // <= 14 waves have a query block
+    const int tq = wave * 16 + qi;
     auto qkv_at = [&](int b, int h, int t, int part, int c) -> const _Float16* {
         if (PACKED) return qkv + pk_offset((long long)b * T + t, part * D + h * 64, 3 * D) + c * 8;
         return qkv + ((size_t)b * T + t) * row_stride + part * D + h * 64 + c * 8;
     };
     constexpr int TROWS = NKB * 16 < ATT_TMAX ? (NKB + (NKB & 1)) * 16 : ATT_TMAX;
     constexpr int SROUNDS = (TROWS * 8 + ATT_P_THREADS - 1) / ATT_P_THREADS;
-    half8 kreg[SROUNDS], vreg[SROUNDS], qn[2][2];
+    half8 kreg[SROUNDS], vreg[SROUNDS], qn[2];
     auto load_item = [&](int item) {
         const int b = item / heads, h = item - b * heads;
 #pragma unroll
@@ -1047,12 +914,9 @@ __global__ __launch_bounds__(ATT_P_THREADS, 2) void k_attention_f16_p(const _Flo
                 vreg[r] = *reinterpret_cast<const half8*>(qkv_at(b, h, t, 2, c));
             }
         }
-        if (active) {
+        if (wave < nqb) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-                    qn[j][kk] = *reinterpret_cast<const half8*>(qkv_at(b, h, min(tq[j], T - 1), 0, kk * 4 + g));
+            for (int kk = 0; kk < 2; ++kk) qn[kk] = *reinterpret_cast<const half8*>(qkv_at(b, h, min(tq, T - 1), 0, kk * 4 + g));
         }
     };
     auto store_item = [&](int buf) {
@@ -1068,45 +932,33 @@ __global__ __launch_bounds__(ATT_P_THREADS, 2) void k_attention_f16_p(const _Flo
             }
         }
     };
-    half8 qf[2][2];
-    auto take_q = [&]() {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qf[j][kk][e] = qn[j][kk][e] * (_Float16)0.125f;  // 1/sqrt(64): exact scaling
-    };
     int item = blockIdx.x;
     if (item >= total) return;
     load_item(item);
     store_item(0);
-    take_q();
+    half8 qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[kk][j] = qn[kk][j] * (_Float16)0.125f;  // 1/sqrt(64): exact scaling
     __syncthreads();
     for (int it = 0;; ++it) {
         const int next = item + (int)gridDim.x;
         const bool more = next < total;
-#ifdef ISC_ABLATION
-        const bool stage = !(g_att_abl & 4);  // ISC_ATT_ABL=4 (timing aid, wrong results): every head reuses the first one's keys / values
-#else
-        constexpr bool stage = true;
-#endif
-        if (more && stage) load_item(next);  // in flight under this head's round
-        if (active) {
+        if (more) load_item(next);  // in flight under this head's round
+        if (wave < nqb) {
             const int b = item / heads, h = item - b * heads;
-            const _Float16* Ks = kv + (stage ? (it & 1) : 0) * IMG;
-            _Float16* orow[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                orow[j] = PACKED ? out + pk_offset((long long)b * T + min(tq[j], T - 1), h * 64, D)
-                                 : out + ((size_t)b * T + min(tq[j], T - 1)) * D + h * 64;
-            att_query_block2<NKB, TAIL>(Ks, Ks + ATT_TMAX * ATT_KSTRIDE, qf, T, tq, qi, g, orow);
+            const _Float16* Ks = kv + (it & 1) * IMG;
+            _Float16* orow = PACKED ? out + pk_offset((long long)b * T + min(tq, T - 1), h * 64, D)
+                                    : out + ((size_t)b * T + min(tq, T - 1)) * D + h * 64;
+            att_query_block<NKB, TAIL>(Ks, Ks + ATT_TMAX * ATT_KSTRIDE, qf, T, tq, qi, g, orow);
         }
         if (!more) break;
-        if (stage) {
-            store_item((it + 1) & 1);  // the image the PREVIOUS head was read from: every wave is past that round's barrier
-            take_q();
-        }
+        store_item((it + 1) & 1);  // the image the PREVIOUS head was read from: every wave is past that round's barrier
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[kk][j] = qn[kk][j] * (_Float16)0.125f;
         __syncthreads();
         item = next;
     }
