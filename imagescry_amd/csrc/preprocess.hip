@@ -406,6 +406,71 @@ extern "C" int isc_normalize_clip(const void* x, int dtype, int B, int C, int H,
     return isc_launch_status();
 }
 
+#ifdef ISC_ABLATION
+static bool normalize_no_transpose() {
+    static const bool v = getenv("ISC_NORMALIZE_NO_TRANSPOSE") != nullptr;  // A/B aid: strided 16-byte stores, as before
+    return v;
+}
+#else
+static constexpr bool normalize_no_transpose() { return false; }
+#endif
+
+// The four-pixels-per-thread form with the stores TRANSPOSED through LDS: a thread still reads its four consecutive pixels of
+// each plane with one load, but a store instruction of k_normalize_nhwc4<T, 4> writes 64 pieces of 16 bytes that lie 64 bytes
+// apart (every 128-byte line is written by four instructions), and the float32 output is 5/6 of this kernel's traffic.  Here
+// the 1 024 pixels of a workgroup pass through 16 KiB of LDS and thread t stores pixels t, t + 256, ...: a wave writes one
+// contiguous KiB per instruction.  Same arithmetic, bit-identical output.
+template <typename T>
+__global__ __launch_bounds__(256) void k_normalize_nhwc4_t(const T* __restrict__ x, size_t ngroups, int C, int HW,
+                                                           const float* __restrict__ mean, const float* __restrict__ stdev,
+                                                           int per_image, float eps, float lo, float hi,
+                                                           float* __restrict__ y) {
+    __shared__ float4 px[1024];
+    const int tid = threadIdx.x;
+    const size_t groups_per_image = (size_t)HW / 4;
+    for (size_t base = (size_t)blockIdx.x * 256; base < ngroups; base += (size_t)gridDim.x * 256) {
+        const size_t g = base + tid;
+        if (g < ngroups) {
+            const size_t b = g / groups_per_image;
+            const size_t hw = (g - b * groups_per_image) * 4;
+            float o[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < C) {
+                    const int st = per_image ? (int)(b * C + c) : c;
+                    const float mu = mean[st];
+                    const float denom = stdev[st] + eps;
+                    const T* src = x + (b * C + c) * (size_t)HW + hw;
+                    T v[4];
+                    if constexpr (sizeof(T) == 1) {
+                        const unsigned w = *reinterpret_cast<const unsigned*>(src);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = (T)((w >> (8 * j)) & 0xffu);
+                    } else {
+                        const float4 w = *reinterpret_cast<const float4*>(src);
+                        v[0] = (T)w.x; v[1] = (T)w.y; v[2] = (T)w.z; v[3] = (T)w.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j][c] = norm_clip((float)v[j], mu, denom, lo, hi);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j][c] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) px[tid * 4 + j] = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+        }
+        __syncthreads();
+        // y is [B][HW][4]: the workgroup's 1 024 pixels are consecutive in it whatever image they belong to
+        const size_t npx = (ngroups - base < 256 ? ngroups - base : 256) * 4;
+        float4* dst = reinterpret_cast<float4*>(y) + base * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((size_t)(j * 256 + tid) < npx) dst[j * 256 + tid] = px[j * 256 + tid];
+        __syncthreads();
+    }
+}
+
 extern "C" int isc_normalize_clip_nhwc4(const void* x, int dtype, int B, int C, int H, int W, const float* mean,
                                         const float* stdev, int stat_batch, float eps, float lo, float hi, float* y,
                                         void* stream) {
@@ -423,11 +488,13 @@ extern "C" int isc_normalize_clip_nhwc4(const void* x, int dtype, int B, int C, 
     const dim3 grid(grid_for(ngroups, 256)), block(256);
     if (dtype == ISC_U8) {
         const uint8_t* p = static_cast<const uint8_t*>(x);
-        if (vec) hipLaunchKernelGGL((k_normalize_nhwc4<uint8_t, 4>), grid, block, 0, s, p, ngroups, C, HW, mean, stdev, per_image, eps, lo, hi, y);
+        if (vec && !normalize_no_transpose()) hipLaunchKernelGGL((k_normalize_nhwc4_t<uint8_t>), grid, block, 0, s, p, ngroups, C, HW, mean, stdev, per_image, eps, lo, hi, y);
+        else if (vec) hipLaunchKernelGGL((k_normalize_nhwc4<uint8_t, 4>), grid, block, 0, s, p, ngroups, C, HW, mean, stdev, per_image, eps, lo, hi, y);
         else hipLaunchKernelGGL((k_normalize_nhwc4<uint8_t, 1>), grid, block, 0, s, p, ngroups, C, HW, mean, stdev, per_image, eps, lo, hi, y);
     } else {
         const float* p = static_cast<const float*>(x);
-        if (vec) hipLaunchKernelGGL((k_normalize_nhwc4<float, 4>), grid, block, 0, s, p, ngroups, C, HW, mean, stdev, per_image, eps, lo, hi, y);
+        if (vec && !normalize_no_transpose()) hipLaunchKernelGGL((k_normalize_nhwc4_t<float>), grid, block, 0, s, p, ngroups, C, HW, mean, stdev, per_image, eps, lo, hi, y);
+        else if (vec) hipLaunchKernelGGL((k_normalize_nhwc4<float, 4>), grid, block, 0, s, p, ngroups, C, HW, mean, stdev, per_image, eps, lo, hi, y);
         else hipLaunchKernelGGL((k_normalize_nhwc4<float, 1>), grid, block, 0, s, p, ngroups, C, HW, mean, stdev, per_image, eps, lo, hi, y);
     }
     return isc_launch_status();
