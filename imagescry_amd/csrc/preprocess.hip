@@ -171,6 +171,29 @@ __global__ __launch_bounds__(256) void k_normalize_u8_vec16(const uint8_t* __res
     }
 }
 
+// 4 pixels per lane: one 4-byte load, ONE 16-byte store -- a wave reads 256 contiguous bytes and writes one contiguous KiB per
+// instruction.  (k_normalize_u8_vec16's four stores per lane each write 64 pieces of 16 bytes 64 bytes apart, every 128-byte
+// line four times over: 116 us against this kernel's ~75 at 512 x 3 x 224 x 224; the 16-pixel form is no longer launched.)
+__global__ __launch_bounds__(256) void k_normalize_u8_vec4(const uint8_t* __restrict__ x, size_t nvec, int C, int HW,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ stdev, int per_image, float eps,
+                                                           float lo, float hi, float* __restrict__ y) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = v * 4;
+        const size_t plane = e / HW;
+        const int st = per_image ? (int)plane : (int)(plane % C);
+        const float mu = mean[st];
+        const float denom = stdev[st] + eps;
+        const unsigned w = *reinterpret_cast<const unsigned*>(x + e);
+        float4 o;
+        o.x = norm_clip((float)(w & 0xffu), mu, denom, lo, hi);
+        o.y = norm_clip((float)((w >> 8) & 0xffu), mu, denom, lo, hi);
+        o.z = norm_clip((float)((w >> 16) & 0xffu), mu, denom, lo, hi);
+        o.w = norm_clip((float)(w >> 24), mu, denom, lo, hi);
+        *reinterpret_cast<float4*>(y + e) = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_normalize_f32_vec4(const float* __restrict__ x, size_t nvec, int C, int HW,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ stdev, int per_image, float eps,
@@ -370,6 +393,15 @@ extern "C" int isc_channel_stats(const void* x, int dtype, int B, int C, int H, 
     return isc_launch_status();
 }
 
+#ifdef ISC_ABLATION
+static bool normalize_vec16() {
+    static const bool v = getenv("ISC_NORMALIZE_VEC16") != nullptr;  // A/B aid: the 16-pixels-per-lane form, as before
+    return v;
+}
+#else
+static constexpr bool normalize_vec16() { return false; }
+#endif
+
 extern "C" int isc_normalize_clip(const void* x, int dtype, int B, int C, int H, int W, const float* mean,
                                   const float* stdev, int stat_batch, float eps, float lo, float hi, float* y,
                                   void* stream) {
@@ -384,7 +416,11 @@ extern "C" int isc_normalize_clip(const void* x, int dtype, int B, int C, int H,
     hipStream_t s = isc_stream(stream);
     if (dtype == ISC_U8) {
         const uint8_t* p = static_cast<const uint8_t*>(x);
-        if (HW % 16 == 0 && isc_aligned(p, 16) && isc_aligned(y, 16)) {
+        if (HW % 4 == 0 && isc_aligned(p, 4) && isc_aligned(y, 16) && !normalize_vec16()) {
+            const size_t nvec = n / 4;
+            hipLaunchKernelGGL(k_normalize_u8_vec4, dim3(grid_for(nvec, 256)), dim3(256), 0, s, p, nvec, C, HW, mean,
+                               stdev, per_image, eps, lo, hi, y);
+        } else if (HW % 16 == 0 && isc_aligned(p, 16) && isc_aligned(y, 16)) {
             const size_t nvec = n / 16;
             hipLaunchKernelGGL(k_normalize_u8_vec16, dim3(grid_for(nvec, 256)), dim3(256), 0, s, p, nvec, C, HW, mean,
                                stdev, per_image, eps, lo, hi, y);
